@@ -1,0 +1,370 @@
+// C-ABI entry points (include/mfgpu.h): handle life cycle, vmult / vmult_add, GpuVector pieces.
+#include <hip/hip_runtime.h>
+
+#include <cmath>
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include "mfgpu_kernels.h"
+
+using namespace mfgpu;
+
+#define HIP_TRY(expr)                                                                    \
+  do {                                                                                   \
+    hipError_t e_ = (expr);                                                              \
+    if (e_ != hipSuccess) {                                                              \
+      set_error(std::string(#expr) + ": " + hipGetErrorString(e_));                      \
+      return e_ == hipErrorOutOfMemory ? MFGPU_ENOMEM : MFGPU_EHIP;                      \
+    }                                                                                    \
+  } while (0)
+
+struct mfgpu_handle {
+  Plan plan;
+  int dim = 0, n = 0, nd = 0, number_type = MFGPU_F64;
+  bool hn = false;
+  std::vector<double> S, Dt;
+  // device arrays
+  uint32_t *d_batch_cell_off = nullptr, *d_batch_dof_off = nullptr, *d_bdofs = nullptr;
+  uint8_t *d_bflags = nullptr;
+  uint16_t *d_lmap = nullptr;
+  void *d_coef = nullptr;
+  uint32_t *d_cmask = nullptr, *d_orphans = nullptr;
+  void *d_hnw = nullptr;
+  size_t lds = 0, device_bytes = 0;
+  // profiling
+  bool prof = false;
+  std::vector<hipEvent_t> ev;  // start/stop pairs
+  size_t ev_used = 0;
+  double prof_ms = 0.0;
+  uint64_t prof_vmults = 0;
+};
+
+namespace {
+
+template <typename P>
+int dev_upload(P **dst, const void *src, size_t bytes, size_t &acct) {
+  *dst = nullptr;
+  if (bytes == 0) return 0;
+  HIP_TRY(hipMalloc((void **)dst, bytes));
+  HIP_TRY(hipMemcpy(*dst, src, bytes, hipMemcpyHostToDevice));
+  acct += bytes;
+  return 0;
+}
+
+// symmetry of the 1D tables (see mfgpu_kernels.hip tab_at); also makes mirrored entries bit-equal
+int check_symmetrize(int n, std::vector<double> &S, std::vector<double> &Dt) {
+  const int p = n - 1;
+  double err = 0, mag = 0;
+  for (int r = 0; r < n; ++r)
+    for (int c = 0; c < n; ++c) {
+      const double s1 = S[r * n + c], s2 = S[(p - r) * n + (p - c)];
+      const double d1 = Dt[r * n + c], d2 = -Dt[(p - r) * n + (p - c)];
+      err = std::fmax(err, std::fmax(std::fabs(s1 - s2), std::fabs(d1 - d2)));
+      mag = std::fmax(mag, std::fmax(std::fabs(s1), std::fabs(d1)));
+    }
+  if (err > 1e-10 * mag) {
+    set_error("shape tables are not symmetric about the cell midpoint (unsupported)");
+    return MFGPU_EUNSUPPORTED;
+  }
+  for (int r = 0; r < n; ++r)
+    for (int c = 0; c < n; ++c) {
+      const int r2 = p - r, c2 = p - c;
+      if (r * n + c < r2 * n + c2) {
+        const double s = 0.5 * (S[r * n + c] + S[r2 * n + c2]);
+        S[r * n + c] = S[r2 * n + c2] = s;
+        const double d = 0.5 * (Dt[r * n + c] - Dt[r2 * n + c2]);
+        Dt[r * n + c] = d;
+        Dt[r2 * n + c2] = -d;
+      } else if (r == r2 && c == c2) {
+        Dt[r * n + c] = 0.0;
+      }
+    }
+  return 0;
+}
+
+template <typename T>
+int create_typed(mfgpu_handle *h, const mfgpu_desc &d) {
+  const Plan &P = h->plan;
+  const size_t ncell = P.n_cells, nd = (size_t)P.nd;
+  size_t &acct = h->device_bytes;
+  int rc;
+  if ((rc = dev_upload(&h->d_batch_cell_off, P.batch_cell_off.data(), P.batch_cell_off.size() * 4, acct))) return rc;
+  if ((rc = dev_upload(&h->d_batch_dof_off, P.batch_dof_off.data(), P.batch_dof_off.size() * 4, acct))) return rc;
+  if ((rc = dev_upload(&h->d_bdofs, P.bdofs.data(), P.bdofs.size() * 4, acct))) return rc;
+  if ((rc = dev_upload(&h->d_bflags, P.bflags.data(), P.bflags.size(), acct))) return rc;
+  if ((rc = dev_upload(&h->d_lmap, P.lmap.data(), P.lmap.size() * 2, acct))) return rc;
+  if ((rc = dev_upload(&h->d_orphans, P.orphans.data(), P.orphans.size() * 4, acct))) return rc;
+  if (h->hn) {
+    std::vector<uint32_t> cm(ncell);
+    for (size_t i = 0; i < ncell; ++i) cm[i] = d.constraint_mask[P.cell_order[i]];
+    if ((rc = dev_upload(&h->d_cmask, cm.data(), ncell * 4, acct))) return rc;
+    std::vector<T> w((size_t)h->n * h->n);
+    for (size_t i = 0; i < w.size(); ++i) w[i] = (T)d.constraint_weights[i];
+    if ((rc = dev_upload((T **)&h->d_hnw, w.data(), w.size() * sizeof(T), acct))) return rc;
+  }
+  // coefficient (given, or evaluated on the device from the quadrature points), then folded
+  size_t tmp = 0;
+  T *t_coef = nullptr, *t_jxw = nullptr, *t_j0 = nullptr, *t_q = nullptr;
+  uint32_t *t_order = nullptr;
+  auto cleanup = [&]() {
+    hipFree(t_coef);
+    hipFree(t_jxw);
+    hipFree(t_j0);
+    hipFree(t_q);
+    hipFree(t_order);
+  };
+  if (d.coefficient) {
+    if ((rc = dev_upload(&t_coef, d.coefficient, ncell * nd * sizeof(T), tmp))) { cleanup(); return rc; }
+  } else {
+    if ((rc = dev_upload(&t_q, d.quadrature_points, ncell * nd * P.dim * sizeof(T), tmp))) { cleanup(); return rc; }
+    hipError_t e = hipMalloc((void **)&t_coef, ncell * nd * sizeof(T));
+    if (e == hipSuccess) e = coefficient_launch<T>(t_coef, t_q, ncell * nd, P.dim, nullptr);
+    if (e != hipSuccess) {
+      set_error(std::string("coefficient evaluation: ") + hipGetErrorString(e));
+      cleanup();
+      return MFGPU_EHIP;
+    }
+  }
+  if ((rc = dev_upload(&t_jxw, d.JxW, ncell * nd * sizeof(T), tmp))) { cleanup(); return rc; }
+  if ((rc = dev_upload(&t_j0, d.inv_jac, ncell * sizeof(T), tmp))) { cleanup(); return rc; }
+  if ((rc = dev_upload(&t_order, P.cell_order.data(), ncell * 4, tmp))) { cleanup(); return rc; }
+  hipError_t e = hipMalloc(&h->d_coef, ncell * nd * sizeof(T));
+  if (e == hipSuccess) {
+    acct += ncell * nd * sizeof(T);
+    e = fold_launch<T>((T *)h->d_coef, t_coef, t_jxw, t_j0, t_order, (uint32_t)ncell, (uint32_t)nd, nullptr);
+  }
+  if (e == hipSuccess) e = hipDeviceSynchronize();
+  cleanup();
+  if (e != hipSuccess) {
+    set_error(std::string("coefficient fold: ") + hipGetErrorString(e));
+    return MFGPU_EHIP;
+  }
+  h->lds = apply_lds_bytes<T>(P.dim, P.n, P.max_batch_dofs);
+  if (h->lds > 160 * 1024) {
+    set_error("batch needs more than 160 KiB of LDS; lower max_dofs_per_batch");
+    return MFGPU_EINVAL;
+  }
+  HIP_TRY(apply_configure<T>(P.dim, P.n, h->lds));
+  return 0;
+}
+
+template <typename T>
+int vmult_typed(mfgpu_handle *h, void *dst, const void *src, hipStream_t st, int add) {
+  const Plan &P = h->plan;
+  ApplyArgs<T> a;
+  a.batch_cell_off = h->d_batch_cell_off;
+  a.batch_dof_off = h->d_batch_dof_off;
+  a.bdofs = h->d_bdofs;
+  a.bflags = h->d_bflags;
+  a.lmap = h->d_lmap;
+  a.coef = (const T *)h->d_coef;
+  a.cmask = h->d_cmask;
+  a.hn_weights = (const T *)h->d_hnw;
+  a.dst = (T *)dst;
+  a.src = (const T *)src;
+  a.nb_max = P.max_batch_dofs;
+  a.add = add;
+  const size_t ncol = P.color_batch_off.size() - 1;
+  for (size_t c = 0; c < ncol; ++c) {
+    a.batch0 = P.color_batch_off[c];
+    const uint32_t nbat = P.color_batch_off[c + 1] - a.batch0;
+    if (nbat == 0) continue;
+    if (h->prof) {
+      if (h->ev_used + 2 > h->ev.size()) {
+        hipEvent_t e0, e1;
+        HIP_TRY(hipEventCreate(&e0));
+        HIP_TRY(hipEventCreate(&e1));
+        h->ev.push_back(e0);
+        h->ev.push_back(e1);
+      }
+      HIP_TRY(hipEventRecord(h->ev[h->ev_used], st));
+    }
+    HIP_TRY(apply_launch<T>(P.dim, P.n, a, h->S.data(), h->Dt.data(), h->hn, nbat, st));
+    if (h->prof) {
+      HIP_TRY(hipEventRecord(h->ev[h->ev_used + 1], st));
+      h->ev_used += 2;
+    }
+  }
+  HIP_TRY(orphan_launch<T>((T *)dst, (const T *)src, h->d_orphans, (uint32_t)P.orphans.size(), add, st));
+  if (h->prof) h->prof_vmults++;
+  return 0;
+}
+
+}  // namespace
+
+extern "C" {
+
+int mfgpu_create(const mfgpu_desc *desc, mfgpu_handle **out) {
+  if (!desc || !out) {
+    set_error("null argument");
+    return MFGPU_EINVAL;
+  }
+  const mfgpu_desc &d = *desc;
+  if (d.number_type != MFGPU_F64 && d.number_type != MFGPU_F32) {
+    set_error("number_type must be MFGPU_F64 or MFGPU_F32");
+    return MFGPU_EINVAL;
+  }
+  if (!(d.flags & MFGPU_UNIFORM_J0)) {
+    set_error("only the MFGPU_UNIFORM_J0 geometry path (one scalar inverse Jacobian per cell, "
+              "reference MATRIX_FREE_UNIFORM_MESH) is implemented");
+    return MFGPU_EUNSUPPORTED;
+  }
+  if (!d.JxW || !d.inv_jac || !d.shape_values || !d.shape_gradients ||
+      (!d.coefficient && !d.quadrature_points)) {
+    set_error("JxW, inv_jac, shape tables and coefficient (or quadrature_points) are required");
+    return MFGPU_EINVAL;
+  }
+  const bool hn = (d.flags & MFGPU_HANGING_NODES) != 0;
+  if (hn && (!d.constraint_mask || !d.constraint_weights)) {
+    set_error("MFGPU_HANGING_NODES needs constraint_mask and constraint_weights");
+    return MFGPU_EINVAL;
+  }
+  mfgpu_handle *h = new mfgpu_handle();
+  int rc = build_plan(d, h->plan);
+  if (rc) {
+    delete h;
+    return rc;
+  }
+  h->dim = d.dim;
+  h->n = d.degree + 1;
+  h->nd = h->plan.nd;
+  h->number_type = d.number_type;
+  h->hn = hn;
+  const int nn = h->n * h->n;
+  std::vector<double> sv(nn), sg(nn);
+  for (int i = 0; i < nn; ++i) {
+    sv[i] = d.number_type == MFGPU_F64 ? ((const double *)d.shape_values)[i] : ((const float *)d.shape_values)[i];
+    sg[i] = d.number_type == MFGPU_F64 ? ((const double *)d.shape_gradients)[i] : ((const float *)d.shape_gradients)[i];
+  }
+  rc = derive_tables(h->n, sv.data(), sg.data(), h->S, h->Dt);
+  if (!rc) rc = check_symmetrize(h->n, h->S, h->Dt);
+  if (!rc) rc = d.number_type == MFGPU_F64 ? create_typed<double>(h, d) : create_typed<float>(h, d);
+  if (rc) {
+    mfgpu_destroy(h);
+    return rc;
+  }
+  *out = h;
+  return 0;
+}
+
+void mfgpu_destroy(mfgpu_handle *h) {
+  if (!h) return;
+  hipFree(h->d_batch_cell_off);
+  hipFree(h->d_batch_dof_off);
+  hipFree(h->d_bdofs);
+  hipFree(h->d_bflags);
+  hipFree(h->d_lmap);
+  hipFree(h->d_coef);
+  hipFree(h->d_cmask);
+  hipFree(h->d_orphans);
+  hipFree(h->d_hnw);
+  for (hipEvent_t e : h->ev) hipEventDestroy(e);
+  delete h;
+}
+
+int mfgpu_vmult(mfgpu_handle *h, void *dst, const void *src, void *stream) {
+  if (!h || !dst || !src) {
+    set_error("null argument");
+    return MFGPU_EINVAL;
+  }
+  if (dst == src) {
+    set_error("vmult: dst and src must not alias");
+    return MFGPU_EINVAL;
+  }
+  return h->number_type == MFGPU_F64 ? vmult_typed<double>(h, dst, src, (hipStream_t)stream, 0)
+                                     : vmult_typed<float>(h, dst, src, (hipStream_t)stream, 0);
+}
+
+int mfgpu_vmult_add(mfgpu_handle *h, void *dst, const void *src, void *stream) {
+  if (!h || !dst || !src) {
+    set_error("null argument");
+    return MFGPU_EINVAL;
+  }
+  if (dst == src) {
+    set_error("vmult_add: dst and src must not alias");
+    return MFGPU_EINVAL;
+  }
+  return h->number_type == MFGPU_F64 ? vmult_typed<double>(h, dst, src, (hipStream_t)stream, 1)
+                                     : vmult_typed<float>(h, dst, src, (hipStream_t)stream, 1);
+}
+
+uint32_t mfgpu_n_dofs(const mfgpu_handle *h) { return h ? h->plan.n_dofs : 0; }
+
+size_t mfgpu_memory_consumption(const mfgpu_handle *h) { return h ? h->device_bytes : 0; }
+
+int mfgpu_plan_stats(const mfgpu_handle *h, uint64_t s[8]) {
+  if (!h || !s) return MFGPU_EINVAL;
+  const Plan &P = h->plan;
+  s[0] = P.batch_cell_off.size() - 1;
+  s[1] = P.color_batch_off.size() - 1;
+  s[2] = P.bdofs.size();
+  s[3] = P.max_batch_dofs;
+  s[4] = P.max_batch_cells;
+  s[5] = P.orphans.size();
+  s[6] = P.n_first;
+  s[7] = P.n_add;
+  return 0;
+}
+
+int mfgpu_profile_enable(mfgpu_handle *h, int on) {
+  if (!h) return MFGPU_EINVAL;
+  h->prof = on != 0;
+  h->ev_used = 0;
+  h->prof_ms = 0.0;
+  h->prof_vmults = 0;
+  return 0;
+}
+
+int mfgpu_profile_read(mfgpu_handle *h, double *ms, uint64_t *nv) {
+  if (!h || !ms || !nv) return MFGPU_EINVAL;
+  HIP_TRY(hipDeviceSynchronize());
+  for (size_t i = 0; i + 1 < h->ev_used; i += 2) {
+    float t = 0.f;
+    HIP_TRY(hipEventElapsedTime(&t, h->ev[i], h->ev[i + 1]));
+    h->prof_ms += t;
+  }
+  h->ev_used = 0;
+  *ms = h->prof_ms;
+  *nv = h->prof_vmults;
+  return 0;
+}
+
+// ---- GpuVector pieces -----------------------------------------------------------------------
+
+static size_t esize(int nt) { return nt == MFGPU_F32 ? 4 : 8; }
+
+int mfgpu_vec_alloc(void **dev, size_t n, int nt) {
+  if (!dev) return MFGPU_EINVAL;
+  *dev = nullptr;
+  if (n == 0) return 0;
+  HIP_TRY(hipMalloc(dev, n * esize(nt)));
+  HIP_TRY(hipMemset(*dev, 0, n * esize(nt)));
+  return 0;
+}
+int mfgpu_vec_free(void *dev) {
+  if (dev) HIP_TRY(hipFree(dev));
+  return 0;
+}
+int mfgpu_vec_fill(void *dev, size_t n, int nt, double value, void *stream) {
+  if (!dev && n) return MFGPU_EINVAL;
+  if (nt == MFGPU_F32)
+    HIP_TRY(fill_launch<float>((float *)dev, n, (float)value, (hipStream_t)stream));
+  else
+    HIP_TRY(fill_launch<double>((double *)dev, n, value, (hipStream_t)stream));
+  return 0;
+}
+int mfgpu_vec_from_host(void *dev, const void *host, size_t n, int nt) {
+  if (n) HIP_TRY(hipMemcpy(dev, host, n * esize(nt), hipMemcpyHostToDevice));
+  return 0;
+}
+int mfgpu_vec_to_host(void *host, const void *dev, size_t n, int nt) {
+  if (n) HIP_TRY(hipMemcpy(host, dev, n * esize(nt), hipMemcpyDeviceToHost));
+  return 0;
+}
+int mfgpu_device_synchronize(void) {
+  HIP_TRY(hipDeviceSynchronize());
+  return 0;
+}
+
+}  // extern "C"

@@ -1,0 +1,59 @@
+// Internal structures shared by the planner (host only), the API layer and the kernels.
+#ifndef MFGPU_INTERNAL_H
+#define MFGPU_INTERNAL_H
+
+#include <cstdint>
+#include <string>
+#include <vector>
+
+#include "../../include/mfgpu.h"
+
+namespace mfgpu {
+
+void set_error(const std::string &msg);
+
+inline int ipow(int a, int e) {
+  int r = 1;
+  for (int i = 0; i < e; ++i) r *= a;
+  return r;
+}
+
+constexpr int kBlock = 256;           // threads per workgroup of the cell-loop kernel (4 waves)
+constexpr uint8_t kFlagConstrained = 1;  // batch dof is a constrained row (identity)
+constexpr uint8_t kFlagAdd = 2;          // batch is NOT the first toucher: dst += (else dst =)
+
+// Host-side execution plan: replaces deal.II GraphColoring + the per-colour arrays of
+// ReinitHelper::init_with_coloring (reference matrix_free_gpu.cu:157-186).  Cells are grouped
+// into batches (one workgroup each); batches, not cells, are coloured.
+struct Plan {
+  int dim = 0, degree = 0, n = 0, nd = 0;
+  uint32_t n_dofs = 0, n_cells = 0;
+  std::vector<uint32_t> cell_order;       // plan position -> caller's cell index
+  std::vector<uint32_t> batch_cell_off;   // [n_batches+1] into plan positions
+  std::vector<uint32_t> batch_dof_off;    // [n_batches+1] into bdofs
+  std::vector<uint32_t> color_batch_off;  // [n_colors+1]
+  std::vector<uint32_t> bdofs;            // ascending global dof ids per batch
+  std::vector<uint8_t> bflags;            // per bdofs entry
+  std::vector<uint16_t> lmap;             // [n_cells*nd] plan order: local dof -> batch-local id
+  std::vector<uint32_t> orphans;          // dofs touched by no cell; bit 31 set = constrained
+  uint32_t max_batch_dofs = 0, max_batch_cells = 0;
+  uint64_t n_first = 0, n_add = 0;
+};
+
+// Build the plan from a description (validates it).  Returns 0 or MFGPU_E*.
+int build_plan(const mfgpu_desc &d, Plan &plan);
+
+// Derive the kernel's 1D tables from the reference-layout tables T[dof*n+q]:
+//   S[i*n+q]  = shape_values (interpolation nodal -> quadrature points)
+//   Dt[q*n+t] = l_t'(x_q): collocation derivative on the quadrature points, from
+//               shape_gradients = S * Dt^T  (phi_i'(x_q) = sum_t phi_i(x_t) l_t'(x_q))
+int derive_tables(int n, const double *shape_values, const double *shape_gradients,
+                  std::vector<double> &S, std::vector<double> &Dt);
+
+}  // namespace mfgpu
+
+struct mfgpu_plan {
+  mfgpu::Plan plan;
+};
+
+#endif

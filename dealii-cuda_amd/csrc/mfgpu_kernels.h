@@ -1,0 +1,53 @@
+// Kernel argument structs + launcher declarations (implemented in mfgpu_kernels.hip).
+#ifndef MFGPU_KERNELS_H
+#define MFGPU_KERNELS_H
+
+#include <hip/hip_runtime.h>
+
+#include "mfgpu_internal.h"
+
+namespace mfgpu {
+
+template <typename T>
+struct ApplyArgs {
+  const uint32_t *batch_cell_off;
+  const uint32_t *batch_dof_off;
+  const uint32_t *bdofs;
+  const uint8_t *bflags;
+  const uint16_t *lmap;
+  const T *coef;          // folded a*J0^2*JxW, plan cell order
+  const uint32_t *cmask;  // plan cell order, or nullptr
+  const T *hn_weights;    // [n*n] W[i*n+j] (device), or nullptr
+  T *dst;
+  const T *src;
+  uint32_t batch0;  // first batch of this launch (colour)
+  uint32_t nb_max;  // LDS layout: max dofs per batch
+  int add;          // vmult_add semantics
+};
+
+// 1D tables, passed by value as kernel arguments (=> scalar registers).
+template <typename T, int n>
+struct Tables {
+  T S[((n + 1) / 2) * n];   // S[i*n+q]  = phi_i(x_q), rows i < (n+1)/2 (rest by symmetry)
+  T Dt[((n + 1) / 2) * n];  // Dt[q*n+t] = l_t'(x_q), rows q < (n+1)/2 (rest by antisymmetry)
+};
+
+template <typename T>
+size_t apply_lds_bytes(int dim, int n, uint32_t nb_max);
+template <typename T>
+hipError_t apply_configure(int dim, int n, size_t lds);
+template <typename T>
+hipError_t apply_launch(int dim, int n, const ApplyArgs<T> &a, const double *S, const double *Dt,
+                        bool hn, uint32_t nbatches, hipStream_t st);
+template <typename T>
+hipError_t orphan_launch(T *dst, const T *src, const uint32_t *orph, uint32_t n, int add, hipStream_t st);
+template <typename T>
+hipError_t coefficient_launch(T *coef, const T *qpts, size_t nq, int dim, hipStream_t st);
+template <typename T>
+hipError_t fold_launch(T *c, const T *coef, const T *jxw, const T *j0, const uint32_t *order,
+                       uint32_t n_cells, uint32_t nd, hipStream_t st);
+template <typename T>
+hipError_t fill_launch(T *v, size_t n, T a, hipStream_t st);
+
+}  // namespace mfgpu
+#endif

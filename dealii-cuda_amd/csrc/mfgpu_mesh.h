@@ -1,0 +1,41 @@
+// Host-side mesh / DoF / constraint stand-in (see mfgpu_mesh.cpp).
+#ifndef MFGPU_MESH_H
+#define MFGPU_MESH_H
+
+#include <vector>
+
+#include "mfgpu_internal.h"
+
+namespace mfgpu {
+
+void gauss_01(int n, std::vector<double> &x, std::vector<double> &w);
+void gll_01(int p, std::vector<double> &x);
+void lagrange_eval(const std::vector<double> &nodes, double x, std::vector<double> &val,
+                   std::vector<double> &der);
+
+struct Mesh {
+  int dim = 0, degree = 0, number_type = MFGPU_F64;
+  uint32_t n_dofs = 0, n_cells = 0;
+  std::vector<double> nodes, xq, wq;  // 1D support points / Gauss points / weights on [0,1]
+  std::vector<double> shape_values, shape_gradients, weights;
+  std::vector<uint32_t> loc2glob, constraint_mask, constrained;
+  std::vector<double> JxW, inv_jac, qpoints, dof_coords;
+  std::vector<uint32_t> iface[2];
+  // Number-typed copies when number_type == F32
+  std::vector<unsigned char> t_JxW, t_inv_jac, t_qpoints, t_sv, t_sg;
+
+  void init_tables();
+  void finalize_typed();
+  void fill_desc(mfgpu_desc &d) const;
+};
+
+int build_uniform(Mesh &M, const uint32_t *nper, double lo, double hi, uint32_t sb, uint32_t se);
+int build_adaptive(Mesh &M, int n_ref);
+
+}  // namespace mfgpu
+
+struct mfgpu_mesh {
+  mfgpu::Mesh mesh;
+};
+
+#endif

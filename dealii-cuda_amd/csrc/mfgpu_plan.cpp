@@ -1,0 +1,337 @@
+// Host-side planner: groups cells into batches (one workgroup each), colours the batches,
+// and decides for every (batch, dof) whether the batch stores (first toucher) or adds.
+//
+// Replaces, MI355X-first, the reference's per-CELL graph colouring (coloring.cc:8-33,
+// matrix_free_gpu.cu:157-186): a batch sums every dof shared by its own cells in LDS, so
+// only dofs on batch surfaces are read-modify-written in global memory, and the first
+// toucher of a dof stores instead of adding, which removes the separate `dst = 0` pass
+// (laplace_operator_gpu.h:221) and the save/load constrained-row kernels
+// (constraint_handler_gpu.cu:247-289) from the hot loop.
+#include <algorithm>
+#include <cmath>
+#include <cstring>
+#include <numeric>
+
+#include "mfgpu_internal.h"
+
+namespace mfgpu {
+
+static thread_local std::string g_err;
+void set_error(const std::string &msg) { g_err = msg; }
+const char *last_error() { return g_err.c_str(); }
+
+int derive_tables(int n, const double *sv, const double *sg, std::vector<double> &S,
+                  std::vector<double> &Dt) {
+  // Solve S * X = G for X = Dt^T (n x n), long double Gaussian elimination with pivoting.
+  std::vector<long double> A(n * n), B(n * n);
+  for (int i = 0; i < n * n; ++i) {
+    A[i] = sv[i];
+    B[i] = sg[i];
+  }
+  for (int c = 0; c < n; ++c) {
+    int piv = c;
+    for (int r = c + 1; r < n; ++r)
+      if (fabsl(A[r * n + c]) > fabsl(A[piv * n + c])) piv = r;
+    if (fabsl(A[piv * n + c]) < 1e-30L) {
+      set_error("shape_values table is singular");
+      return MFGPU_EINVAL;
+    }
+    if (piv != c)
+      for (int k = 0; k < n; ++k) {
+        std::swap(A[c * n + k], A[piv * n + k]);
+        std::swap(B[c * n + k], B[piv * n + k]);
+      }
+    for (int r = 0; r < n; ++r) {
+      if (r == c) continue;
+      long double f = A[r * n + c] / A[c * n + c];
+      for (int k = 0; k < n; ++k) {
+        A[r * n + k] -= f * A[c * n + k];
+        B[r * n + k] -= f * B[c * n + k];
+      }
+    }
+  }
+  S.assign(sv, sv + n * n);
+  Dt.resize(n * n);
+  // X[t][q] = B[t][q]/A[t][t];  Dt[q*n+t] = X[t][q]
+  for (int t = 0; t < n; ++t)
+    for (int q = 0; q < n; ++q) Dt[q * n + t] = (double)(B[t * n + q] / A[t * n + t]);
+  return 0;
+}
+
+static void default_batch_limits(const mfgpu_desc &d, uint32_t &max_cells, uint32_t &max_dofs) {
+  const int p = d.degree, dim = d.dim;
+  max_dofs = d.max_dofs_per_batch ? d.max_dofs_per_batch : 2304u;
+  if (max_dofs > 65535u) max_dofs = 65535u;  // lmap is 16 bit
+  const uint32_t nd = (uint32_t)ipow(p + 1, dim);
+  if (max_dofs < nd) max_dofs = nd;
+  if (d.max_cells_per_batch) {
+    max_cells = d.max_cells_per_batch;
+  } else {
+    int m = 1;
+    while ((uint64_t)ipow((m + 1) * p + 1, dim) <= max_dofs) ++m;
+    max_cells = (uint32_t)std::min(ipow(m, dim), 64);
+    // keep enough workgroups per launch on small meshes
+    const uint32_t cap = std::max<uint32_t>(1u, d.n_cells / 4096u);
+    max_cells = std::min(max_cells, cap);
+  }
+  if (max_cells < 1) max_cells = 1;
+}
+
+int build_plan(const mfgpu_desc &d, Plan &P) {
+  if (d.dim != 2 && d.dim != 3) {
+    set_error("dim must be 2 or 3");
+    return MFGPU_EINVAL;
+  }
+  if (d.degree < 1 || d.degree > 6) {
+    set_error("degree must be in 1..6");
+    return MFGPU_EUNSUPPORTED;
+  }
+  if (!d.loc2glob || d.n_cells == 0 || d.n_dofs == 0) {
+    set_error("empty description (n_cells, n_dofs and loc2glob are required)");
+    return MFGPU_EINVAL;
+  }
+  if (d.n_constrained && !d.constrained_dofs) {
+    set_error("n_constrained > 0 but constrained_dofs is NULL");
+    return MFGPU_EINVAL;
+  }
+  P.dim = d.dim;
+  P.degree = d.degree;
+  P.n = d.degree + 1;
+  P.nd = ipow(P.n, d.dim);
+  P.n_dofs = d.n_dofs;
+  P.n_cells = d.n_cells;
+  const uint32_t nd = (uint32_t)P.nd, nc = d.n_cells, N = d.n_dofs;
+  const uint32_t *l2g = d.loc2glob;
+
+  for (uint64_t i = 0; i < (uint64_t)nc * nd; ++i)
+    if (l2g[i] >= N) {
+      set_error("loc2glob entry out of range");
+      return MFGPU_EINVAL;
+    }
+  std::vector<uint8_t> constrained(N, 0);
+  for (uint32_t i = 0; i < d.n_constrained; ++i) {
+    if (d.constrained_dofs[i] >= N) {
+      set_error("constrained_dofs entry out of range");
+      return MFGPU_EINVAL;
+    }
+    constrained[d.constrained_dofs[i]] = 1;
+  }
+
+  uint32_t Bmax, NBmax;
+  default_batch_limits(d, Bmax, NBmax);
+
+  // dof -> cells incidence (CSR)
+  std::vector<uint32_t> dc_off(N + 1, 0);
+  for (uint64_t i = 0; i < (uint64_t)nc * nd; ++i) dc_off[l2g[i] + 1]++;
+  for (uint32_t g = 0; g < N; ++g) dc_off[g + 1] += dc_off[g];
+  std::vector<uint32_t> dc(dc_off[N]);
+  {
+    std::vector<uint32_t> pos(dc_off.begin(), dc_off.end() - 1);
+    for (uint32_t c = 0; c < nc; ++c)
+      for (uint32_t i = 0; i < nd; ++i) dc[pos[l2g[(uint64_t)c * nd + i]]++] = c;
+  }
+
+  // ---- greedy batching: grow from the lowest unassigned cell, always adding the candidate that
+  // shares most dofs with the batch (ties: earliest discovered), until a limit is hit.
+  constexpr uint32_t NONE = 0xffffffffu;
+  std::vector<uint32_t> cell_batch(nc, NONE);
+  std::vector<uint32_t> dof_stamp(N, NONE);   // batch id that already contains this dof
+  std::vector<uint32_t> gain(nc, 0), gain_stamp(nc, NONE);
+  std::vector<uint32_t> cand;
+  std::vector<std::vector<uint32_t>> batches;
+  uint32_t seed = 0;
+  while (true) {
+    while (seed < nc && cell_batch[seed] != NONE) ++seed;
+    if (seed >= nc) break;
+    const uint32_t b = (uint32_t)batches.size();
+    batches.emplace_back();
+    std::vector<uint32_t> &cells = batches.back();
+    cand.clear();
+    uint32_t ndofs = 0;
+    uint32_t next = seed;
+    while (true) {
+      // add `next`
+      cell_batch[next] = b;
+      cells.push_back(next);
+      for (uint32_t i = 0; i < nd; ++i) {
+        const uint32_t g = l2g[(uint64_t)next * nd + i];
+        if (dof_stamp[g] == b) continue;
+        dof_stamp[g] = b;
+        ++ndofs;
+        if (Bmax == 1) continue;
+        for (uint32_t k = dc_off[g]; k < dc_off[g + 1]; ++k) {
+          const uint32_t c2 = dc[k];
+          if (cell_batch[c2] != NONE) continue;
+          if (gain_stamp[c2] != b) {
+            gain_stamp[c2] = b;
+            gain[c2] = 0;
+            cand.push_back(c2);
+          }
+          gain[c2]++;
+        }
+      }
+      if (cells.size() >= Bmax) break;
+      // pick best candidate
+      uint32_t best = NONE, best_gain = 0;
+      size_t w = 0;
+      for (size_t k = 0; k < cand.size(); ++k) {
+        const uint32_t c2 = cand[k];
+        if (cell_batch[c2] != NONE) continue;  // was taken
+        cand[w++] = c2;
+        if (gain[c2] > best_gain) {
+          best_gain = gain[c2];
+          best = c2;
+        }
+      }
+      cand.resize(w);
+      if (best == NONE) break;
+      if (ndofs + (nd - best_gain) > NBmax) break;
+      next = best;
+    }
+  }
+  const uint32_t nb = (uint32_t)batches.size();
+
+  // ---- per batch: sorted unique dofs
+  std::vector<std::vector<uint32_t>> bd(nb);
+  for (uint32_t b = 0; b < nb; ++b) {
+    std::vector<uint32_t> &v = bd[b];
+    v.reserve(batches[b].size() * nd);
+    for (uint32_t c : batches[b])
+      for (uint32_t i = 0; i < nd; ++i) v.push_back(l2g[(uint64_t)c * nd + i]);
+    std::sort(v.begin(), v.end());
+    v.erase(std::unique(v.begin(), v.end()), v.end());
+    if (v.size() > 65535u) {
+      set_error("internal: batch exceeds 65535 dofs");
+      return MFGPU_EINVAL;
+    }
+  }
+
+  // ---- greedy colouring of batches (conflict = shared dof)
+  std::vector<uint64_t> dof_colors(N, 0);
+  std::vector<uint32_t> bcolor(nb, 0);
+  uint32_t ncolors = 0;
+  for (uint32_t b = 0; b < nb; ++b) {
+    uint64_t forbidden = 0;
+    for (uint32_t g : bd[b]) forbidden |= dof_colors[g];
+    uint32_t c = 0;
+    while (c < 64 && (forbidden >> c) & 1) ++c;
+    if (c >= 64) {
+      set_error("more than 64 batch colours needed");
+      return MFGPU_EUNSUPPORTED;
+    }
+    bcolor[b] = c;
+    ncolors = std::max(ncolors, c + 1);
+    for (uint32_t g : bd[b]) dof_colors[g] |= (1ull << c);
+  }
+  // execution order: colour-major, stable
+  std::vector<uint32_t> order(nb);
+  std::iota(order.begin(), order.end(), 0u);
+  std::stable_sort(order.begin(), order.end(),
+                   [&](uint32_t a, uint32_t b2) { return bcolor[a] < bcolor[b2]; });
+
+  P.color_batch_off.assign(ncolors + 1, 0);
+  for (uint32_t b = 0; b < nb; ++b) P.color_batch_off[bcolor[b] + 1]++;
+  for (uint32_t c = 0; c < ncolors; ++c) P.color_batch_off[c + 1] += P.color_batch_off[c];
+
+  // ---- emit arrays in execution order
+  P.cell_order.clear();
+  P.cell_order.reserve(nc);
+  P.batch_cell_off.assign(1, 0);
+  P.batch_dof_off.assign(1, 0);
+  P.bdofs.clear();
+  P.bflags.clear();
+  P.lmap.assign((size_t)nc * nd, 0);
+  std::vector<uint8_t> touched(N, 0);
+  P.max_batch_dofs = P.max_batch_cells = 0;
+  P.n_first = P.n_add = 0;
+  for (uint32_t k = 0; k < nb; ++k) {
+    const uint32_t b = order[k];
+    const std::vector<uint32_t> &v = bd[b];
+    for (uint32_t g : v) {
+      uint8_t f = 0;
+      if (constrained[g]) f |= kFlagConstrained;
+      if (touched[g]) {
+        f |= kFlagAdd;
+        ++P.n_add;
+      } else {
+        touched[g] = 1;
+        ++P.n_first;
+      }
+      P.bdofs.push_back(g);
+      P.bflags.push_back(f);
+    }
+    for (uint32_t c : batches[b]) {
+      const size_t pos = P.cell_order.size();
+      P.cell_order.push_back(c);
+      for (uint32_t i = 0; i < nd; ++i) {
+        const uint32_t g = l2g[(uint64_t)c * nd + i];
+        P.lmap[pos * nd + i] = (uint16_t)(std::lower_bound(v.begin(), v.end(), g) - v.begin());
+      }
+    }
+    P.batch_cell_off.push_back((uint32_t)P.cell_order.size());
+    P.batch_dof_off.push_back((uint32_t)P.bdofs.size());
+    P.max_batch_dofs = std::max<uint32_t>(P.max_batch_dofs, (uint32_t)v.size());
+    P.max_batch_cells = std::max<uint32_t>(P.max_batch_cells, (uint32_t)batches[b].size());
+  }
+  P.orphans.clear();
+  for (uint32_t g = 0; g < N; ++g)
+    if (!touched[g]) P.orphans.push_back(g | (constrained[g] ? 0x80000000u : 0u));
+  if (N >= 0x80000000u && !P.orphans.empty()) {
+    set_error("n_dofs >= 2^31 with orphan dofs is not supported");
+    return MFGPU_EUNSUPPORTED;
+  }
+  return 0;
+}
+
+}  // namespace mfgpu
+
+extern "C" {
+
+const char *mfgpu_last_error(void) { return mfgpu::last_error(); }
+
+int mfgpu_plan_create(const mfgpu_desc *desc, mfgpu_plan **out) {
+  if (!desc || !out) {
+    mfgpu::set_error("null argument");
+    return MFGPU_EINVAL;
+  }
+  mfgpu_plan *p = new mfgpu_plan();
+  int rc = mfgpu::build_plan(*desc, p->plan);
+  if (rc) {
+    delete p;
+    return rc;
+  }
+  *out = p;
+  return 0;
+}
+
+void mfgpu_plan_destroy(mfgpu_plan *p) { delete p; }
+
+int64_t mfgpu_plan_array_u32(const mfgpu_plan *p, int what, const uint32_t **ptr) {
+  if (!p || !ptr) return MFGPU_EINVAL;
+  const std::vector<uint32_t> *v = nullptr;
+  switch (what) {
+    case 0: v = &p->plan.batch_cell_off; break;
+    case 1: v = &p->plan.batch_dof_off; break;
+    case 2: v = &p->plan.color_batch_off; break;
+    case 3: v = &p->plan.cell_order; break;
+    case 4: v = &p->plan.bdofs; break;
+    case 5: v = &p->plan.orphans; break;
+    default: mfgpu::set_error("bad array id"); return MFGPU_EINVAL;
+  }
+  *ptr = v->data();
+  return (int64_t)v->size();
+}
+
+int64_t mfgpu_plan_lmap(const mfgpu_plan *p, const uint16_t **ptr) {
+  if (!p || !ptr) return MFGPU_EINVAL;
+  *ptr = p->plan.lmap.data();
+  return (int64_t)p->plan.lmap.size();
+}
+
+int64_t mfgpu_plan_bflags(const mfgpu_plan *p, const uint8_t **ptr) {
+  if (!p || !ptr) return MFGPU_EINVAL;
+  *ptr = p->plan.bflags.data();
+  return (int64_t)p->plan.bflags.size();
+}
+
+}  // extern "C"

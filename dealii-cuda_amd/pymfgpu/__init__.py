@@ -1,0 +1,353 @@
+"""ctypes binding of the C-ABI in include/mfgpu.h (test / bench harness plumbing).
+
+The product is the shared library dealii-cuda_amd/lib/libmfgpu.so (hand-written HIP kernels
+behind a C-ABI) and the C++ shim in dealii-cuda_amd/host/.  This module only loads that library;
+it has NO fallback: if the library is missing or a call fails it raises.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(os.path.dirname(_HERE), "lib", "libmfgpu.so")
+
+F64, F32 = 0, 1
+UNIFORM_J0, HANGING_NODES = 1, 2
+
+
+class MfgpuError(RuntimeError):
+    pass
+
+
+class Desc(C.Structure):
+    """mirror of struct mfgpu_desc"""
+    _fields_ = [
+        ("dim", C.c_int32), ("degree", C.c_int32), ("number_type", C.c_int32), ("flags", C.c_uint32),
+        ("n_dofs", C.c_uint32), ("n_cells", C.c_uint32),
+        ("loc2glob", C.c_void_p), ("constraint_mask", C.c_void_p),
+        ("JxW", C.c_void_p), ("inv_jac", C.c_void_p), ("coefficient", C.c_void_p),
+        ("quadrature_points", C.c_void_p), ("shape_values", C.c_void_p), ("shape_gradients", C.c_void_p),
+        ("constraint_weights", C.c_void_p), ("constrained_dofs", C.c_void_p),
+        ("n_constrained", C.c_uint32), ("max_cells_per_batch", C.c_uint32), ("max_dofs_per_batch", C.c_uint32),
+    ]
+
+
+# every symbol include/mfgpu.h declares (tests check that the library exports all of them)
+SYMBOLS = [
+    "mfgpu_create", "mfgpu_vmult", "mfgpu_vmult_add", "mfgpu_n_dofs", "mfgpu_memory_consumption",
+    "mfgpu_destroy", "mfgpu_last_error", "mfgpu_plan_stats", "mfgpu_profile_enable", "mfgpu_profile_read",
+    "mfgpu_plan_create", "mfgpu_plan_destroy", "mfgpu_plan_array_u32", "mfgpu_plan_lmap", "mfgpu_plan_bflags",
+    "mfgpu_vec_alloc", "mfgpu_vec_free", "mfgpu_vec_fill", "mfgpu_vec_from_host", "mfgpu_vec_to_host",
+    "mfgpu_device_synchronize", "mfgpu_mesh_create_uniform", "mfgpu_mesh_create_adaptive", "mfgpu_mesh_destroy",
+    "mfgpu_mesh_desc", "mfgpu_mesh_dof_coords", "mfgpu_mesh_interface_dofs",
+]
+
+_lib = None
+
+
+def lib():
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise MfgpuError(f"{LIB_PATH} not found: build it with __graft_entry__.build() "
+                             "(make -C dealii-cuda_amd); there is no fallback path")
+        L = C.CDLL(LIB_PATH)
+        L.mfgpu_last_error.restype = C.c_char_p
+        L.mfgpu_create.argtypes = [C.POINTER(Desc), C.POINTER(C.c_void_p)]
+        L.mfgpu_vmult.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
+        L.mfgpu_vmult_add.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
+        L.mfgpu_n_dofs.argtypes = [C.c_void_p]
+        L.mfgpu_n_dofs.restype = C.c_uint32
+        L.mfgpu_memory_consumption.argtypes = [C.c_void_p]
+        L.mfgpu_memory_consumption.restype = C.c_size_t
+        L.mfgpu_destroy.argtypes = [C.c_void_p]
+        L.mfgpu_destroy.restype = None
+        L.mfgpu_plan_stats.argtypes = [C.c_void_p, C.POINTER(C.c_uint64)]
+        L.mfgpu_profile_enable.argtypes = [C.c_void_p, C.c_int]
+        L.mfgpu_profile_read.argtypes = [C.c_void_p, C.POINTER(C.c_double), C.POINTER(C.c_uint64)]
+        L.mfgpu_plan_create.argtypes = [C.POINTER(Desc), C.POINTER(C.c_void_p)]
+        L.mfgpu_plan_destroy.argtypes = [C.c_void_p]
+        L.mfgpu_plan_destroy.restype = None
+        L.mfgpu_plan_array_u32.argtypes = [C.c_void_p, C.c_int, C.POINTER(C.c_void_p)]
+        L.mfgpu_plan_array_u32.restype = C.c_int64
+        L.mfgpu_plan_lmap.argtypes = [C.c_void_p, C.POINTER(C.c_void_p)]
+        L.mfgpu_plan_lmap.restype = C.c_int64
+        L.mfgpu_plan_bflags.argtypes = [C.c_void_p, C.POINTER(C.c_void_p)]
+        L.mfgpu_plan_bflags.restype = C.c_int64
+        L.mfgpu_vec_alloc.argtypes = [C.POINTER(C.c_void_p), C.c_size_t, C.c_int]
+        L.mfgpu_vec_free.argtypes = [C.c_void_p]
+        L.mfgpu_vec_fill.argtypes = [C.c_void_p, C.c_size_t, C.c_int, C.c_double, C.c_void_p]
+        L.mfgpu_vec_from_host.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_int]
+        L.mfgpu_vec_to_host.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_int]
+        L.mfgpu_mesh_create_uniform.argtypes = [C.c_int, C.c_int, C.POINTER(C.c_uint32), C.c_double, C.c_double,
+                                                C.c_uint32, C.c_uint32, C.c_int, C.POINTER(C.c_void_p)]
+        L.mfgpu_mesh_create_adaptive.argtypes = [C.c_int, C.c_int, C.c_int, C.c_int, C.POINTER(C.c_void_p)]
+        L.mfgpu_mesh_destroy.argtypes = [C.c_void_p]
+        L.mfgpu_mesh_destroy.restype = None
+        L.mfgpu_mesh_desc.argtypes = [C.c_void_p, C.POINTER(Desc)]
+        L.mfgpu_mesh_dof_coords.argtypes = [C.c_void_p, C.POINTER(C.c_void_p)]
+        L.mfgpu_mesh_dof_coords.restype = C.c_int64
+        L.mfgpu_mesh_interface_dofs.argtypes = [C.c_void_p, C.c_int, C.POINTER(C.c_void_p)]
+        L.mfgpu_mesh_interface_dofs.restype = C.c_int64
+        _lib = L
+    return _lib
+
+
+def _check(rc):
+    if rc != 0:
+        raise MfgpuError(f"mfgpu error {rc}: {lib().mfgpu_last_error().decode()}")
+
+
+def np_dtype(number_type):
+    return np.float64 if number_type == F64 else np.float32
+
+
+def _view(ptr, count, dtype):
+    if count <= 0 or not ptr:
+        return np.zeros(0, dtype=dtype)
+    buf = (C.c_char * (count * np.dtype(dtype).itemsize)).from_address(ptr)
+    return np.frombuffer(buf, dtype=dtype, count=count)
+
+
+class Mesh:
+    """Host-side stand-in for Triangulation + DoFHandler + ConstraintMatrix (mfgpu_mesh_*)."""
+
+    def __init__(self, handle, keep=None):
+        self._h = handle
+        self._keep = keep
+        self.desc = Desc()
+        _check(lib().mfgpu_mesh_desc(self._h, C.byref(self.desc)))
+
+    @classmethod
+    def uniform(cls, dim, degree, n_per_dir, lo=-1.0, hi=1.0, slab=(0, 0), number_type=F64):
+        if np.isscalar(n_per_dir):
+            n_per_dir = [int(n_per_dir)] * dim
+        arr = (C.c_uint32 * 3)(*(list(n_per_dir) + [1] * (3 - len(n_per_dir))))
+        h = C.c_void_p()
+        _check(lib().mfgpu_mesh_create_uniform(dim, degree, arr, lo, hi, slab[0], slab[1], number_type, C.byref(h)))
+        return cls(h)
+
+    @classmethod
+    def adaptive(cls, dim, degree, n_ref, number_type=F64):
+        h = C.c_void_p()
+        _check(lib().mfgpu_mesh_create_adaptive(dim, degree, n_ref, number_type, C.byref(h)))
+        return cls(h)
+
+    def __del__(self):
+        if getattr(self, "_h", None):
+            lib().mfgpu_mesh_destroy(self._h)
+            self._h = None
+
+    # ---- numpy views of the description arrays (valid while the mesh lives)
+    @property
+    def n_dofs(self):
+        return int(self.desc.n_dofs)
+
+    @property
+    def n_cells(self):
+        return int(self.desc.n_cells)
+
+    @property
+    def nd(self):
+        return (self.desc.degree + 1) ** self.desc.dim
+
+    def arrays(self):
+        d = self.desc
+        dt = np_dtype(d.number_type)
+        nd, nc, n = self.nd, d.n_cells, d.degree + 1
+        out = dict(
+            loc2glob=_view(d.loc2glob, nc * nd, np.uint32).reshape(nc, nd),
+            JxW=_view(d.JxW, nc * nd, dt).reshape(nc, nd),
+            inv_jac=_view(d.inv_jac, nc, dt),
+            quadrature_points=_view(d.quadrature_points, nc * nd * d.dim, dt).reshape(nc, nd, d.dim),
+            shape_values=_view(d.shape_values, n * n, dt),
+            shape_gradients=_view(d.shape_gradients, n * n, dt),
+            constraint_weights=_view(d.constraint_weights, n * n, np.float64),
+            constrained_dofs=_view(d.constrained_dofs, d.n_constrained, np.uint32),
+            constraint_mask=_view(d.constraint_mask, nc, np.uint32) if d.constraint_mask else None,
+        )
+        return out
+
+    def dof_coords(self):
+        p = C.c_void_p()
+        cnt = lib().mfgpu_mesh_dof_coords(self._h, C.byref(p))
+        return _view(p.value, cnt, np.float64).reshape(-1, self.desc.dim)
+
+    def interface_dofs(self, which):
+        p = C.c_void_p()
+        cnt = lib().mfgpu_mesh_interface_dofs(self._h, which, C.byref(p))
+        return _view(p.value, cnt, np.uint32).copy()
+
+
+def make_desc(dim, degree, n_dofs, loc2glob, JxW, inv_jac, coefficient, constrained,
+              shape_values, shape_gradients, number_type=F64, constraint_mask=None,
+              constraint_weights=None, quadrature_points=None, max_cells_per_batch=0, max_dofs_per_batch=0):
+    """Build a Desc from numpy arrays; returns (desc, keepalive list)."""
+    dt = np_dtype(number_type)
+    keep = []
+
+    def ptr(a, dtype):
+        if a is None:
+            return None
+        a = np.ascontiguousarray(a, dtype=dtype)
+        keep.append(a)
+        return a.ctypes.data
+
+    d = Desc()
+    d.dim, d.degree, d.number_type = dim, degree, number_type
+    d.flags = UNIFORM_J0 | (HANGING_NODES if constraint_mask is not None else 0)
+    l2g = np.ascontiguousarray(loc2glob, dtype=np.uint32)
+    d.n_dofs = int(n_dofs)
+    d.n_cells = l2g.size // ((degree + 1) ** dim)
+    d.loc2glob = ptr(l2g, np.uint32)
+    d.constraint_mask = ptr(constraint_mask, np.uint32)
+    d.JxW = ptr(JxW, dt)
+    d.inv_jac = ptr(inv_jac, dt)
+    d.coefficient = ptr(coefficient, dt)
+    d.quadrature_points = ptr(quadrature_points, dt)
+    d.shape_values = ptr(shape_values, dt)
+    d.shape_gradients = ptr(shape_gradients, dt)
+    d.constraint_weights = ptr(constraint_weights, np.float64)
+    c = np.ascontiguousarray(constrained, dtype=np.uint32)
+    d.constrained_dofs = ptr(c, np.uint32)
+    d.n_constrained = c.size
+    d.max_cells_per_batch = max_cells_per_batch
+    d.max_dofs_per_batch = max_dofs_per_batch
+    return d, keep
+
+
+class Plan:
+    """Host-only plan (no GPU): mfgpu_plan_*"""
+
+    def __init__(self, desc: Desc, keep=None):
+        self._keep = keep
+        self.nd = (desc.degree + 1) ** desc.dim
+        h = C.c_void_p()
+        _check(lib().mfgpu_plan_create(C.byref(desc), C.byref(h)))
+        self._h = h
+
+    def __del__(self):
+        if getattr(self, "_h", None):
+            lib().mfgpu_plan_destroy(self._h)
+            self._h = None
+
+    def _u32(self, what):
+        p = C.c_void_p()
+        cnt = lib().mfgpu_plan_array_u32(self._h, what, C.byref(p))
+        if cnt < 0:
+            _check(int(cnt))
+        return _view(p.value, cnt, np.uint32).copy()
+
+    batch_cell_off = property(lambda s: s._u32(0))
+    batch_dof_off = property(lambda s: s._u32(1))
+    color_batch_off = property(lambda s: s._u32(2))
+    cell_order = property(lambda s: s._u32(3))
+    bdofs = property(lambda s: s._u32(4))
+    orphans = property(lambda s: s._u32(5))
+
+    @property
+    def lmap(self):
+        p = C.c_void_p()
+        cnt = lib().mfgpu_plan_lmap(self._h, C.byref(p))
+        return _view(p.value, cnt, np.uint16).reshape(-1, self.nd).copy()
+
+    @property
+    def bflags(self):
+        p = C.c_void_p()
+        cnt = lib().mfgpu_plan_bflags(self._h, C.byref(p))
+        return _view(p.value, cnt, np.uint8).copy()
+
+
+class DeviceVector:
+    """GpuVector<Number> pieces on the path (gpu_vec.h): owning device buffer."""
+
+    def __init__(self, n, number_type=F64):
+        self.n, self.number_type = int(n), number_type
+        p = C.c_void_p()
+        _check(lib().mfgpu_vec_alloc(C.byref(p), self.n, number_type))
+        self.ptr = p.value
+
+    def __del__(self):
+        if getattr(self, "ptr", None):
+            lib().mfgpu_vec_free(self.ptr)
+            self.ptr = None
+
+    def fill(self, value, stream=None):
+        _check(lib().mfgpu_vec_fill(self.ptr, self.n, self.number_type, float(value), stream))
+
+    def from_host(self, a):
+        a = np.ascontiguousarray(a, dtype=np_dtype(self.number_type))
+        assert a.size == self.n
+        _check(lib().mfgpu_vec_from_host(self.ptr, a.ctypes.data, self.n, self.number_type))
+
+    def to_host(self):
+        a = np.empty(self.n, dtype=np_dtype(self.number_type))
+        _check(lib().mfgpu_vec_to_host(a.ctypes.data, self.ptr, self.n, self.number_type))
+        return a
+
+    def swap(self, other):
+        self.ptr, other.ptr = other.ptr, self.ptr
+        self.n, other.n = other.n, self.n
+
+
+class Operator:
+    """LaplaceOperatorGpu surface over the C-ABI handle."""
+
+    def __init__(self, desc: Desc, keep=None):
+        self._keep = keep
+        self.number_type = desc.number_type
+        h = C.c_void_p()
+        _check(lib().mfgpu_create(C.byref(desc), C.byref(h)))
+        self._h = h
+
+    def __del__(self):
+        self.clear()
+
+    def clear(self):
+        if getattr(self, "_h", None):
+            lib().mfgpu_destroy(self._h)
+            self._h = None
+
+    def n(self):
+        return int(lib().mfgpu_n_dofs(self._h))
+
+    m = n
+
+    def vmult(self, dst, src, stream=None):
+        _check(lib().mfgpu_vmult(self._h, _ptr(dst), _ptr(src), stream))
+
+    def vmult_add(self, dst, src, stream=None):
+        _check(lib().mfgpu_vmult_add(self._h, _ptr(dst), _ptr(src), stream))
+
+    def memory_consumption(self):
+        return int(lib().mfgpu_memory_consumption(self._h))
+
+    def plan_stats(self):
+        s = (C.c_uint64 * 8)()
+        _check(lib().mfgpu_plan_stats(self._h, s))
+        keys = ["n_batches", "n_colors", "batch_dofs", "max_batch_dofs", "max_batch_cells", "n_orphans",
+                "first_touch", "rmw_adds"]
+        return dict(zip(keys, [int(v) for v in s]))
+
+    def profile_enable(self, on=True):
+        _check(lib().mfgpu_profile_enable(self._h, int(on)))
+
+    def profile_read(self):
+        ms, nv = C.c_double(), C.c_uint64()
+        _check(lib().mfgpu_profile_read(self._h, C.byref(ms), C.byref(nv)))
+        return ms.value, int(nv.value)
+
+
+def _ptr(v):
+    if isinstance(v, DeviceVector):
+        return v.ptr
+    if hasattr(v, "data_ptr"):  # torch tensor on the GPU
+        return v.data_ptr()
+    return int(v)
+
+
+def synchronize():
+    _check(lib().mfgpu_device_synchronize())

@@ -1,0 +1,165 @@
+/* mfgpu.h -- C-ABI of the MI355X-native matrix-free Laplace operator apply.
+ *
+ * Drop-in boundary for ONE hot path of kalj/dealii-cuda: LaplaceOperatorGpu::vmult
+ * (reference laplace_operator_gpu.h:216-223) as driven by bmop.cu:134-153.
+ *
+ * The reference has no FFI layer: its boundary is a C++ template API whose inputs come
+ * from deal.II (DoFHandler, ConstraintMatrix, FEValues, ShapeInfo).  deal.II objects cannot
+ * cross a C-ABI, so this ABI sits exactly at the OUTPUT of MatrixFreeGpu::reinit
+ * (matrix_free_gpu.cu:448-563) and ConstraintHandlerGpu::reinit
+ * (constraint_handler_gpu.cu:68-95): plain host arrays, plain device pointers, sizes.
+ * All file:line citations are relative to the reference tree.
+ *
+ * Conventions: every function returns 0 on success or a negative MFGPU_E* code (no C++
+ * exception crosses the boundary; the reference throws dealii::ExcMessage,
+ * cuda_utils.cuh:15-25); mfgpu_last_error() gives the message of the calling thread's
+ * last failure.  Handles are independent (no process-global shape tables, unlike
+ * matrix_free_gpu.h:45-48), thread-compatible, not thread-safe per handle.
+ * `stream` arguments are hipStream_t passed as void* (NULL = default stream).
+ */
+#ifndef MFGPU_H
+#define MFGPU_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define MFGPU_OK 0
+#define MFGPU_EINVAL (-1)   /* bad argument / inconsistent description        */
+#define MFGPU_EHIP (-2)     /* HIP runtime error (message has the HIP string) */
+#define MFGPU_ENOMEM (-3)
+#define MFGPU_EUNSUPPORTED (-4) /* (dim, degree, number type) not instantiated */
+
+/* number_type */
+#define MFGPU_F64 0
+#define MFGPU_F32 1 /* reference: -DBMOP_USE_FLOATS, bmop.cu:60-64 */
+
+/* flags */
+#define MFGPU_UNIFORM_J0 (1u << 0)    /* inv_jac holds ONE scalar J^-1[0][0] per cell
+                                         (MATRIX_FREE_UNIFORM_MESH, matrix_free_gpu.cu:332-334,
+                                         fee_gpu.cuh:225-241)                                   */
+#define MFGPU_HANGING_NODES (1u << 1) /* constraint_mask is given (MATRIX_FREE_HANGING_NODES,
+                                         fee_gpu.cuh:333-335,349-351)                           */
+
+typedef struct mfgpu_handle mfgpu_handle; /* replaces MatrixFreeGpu + coefficient + ConstraintHandlerGpu
+                                             inside LaplaceOperatorGpu (laplace_operator_gpu.h:85-95) */
+
+/* Output of MatrixFreeGpu::reinit / ConstraintHandlerGpu::reinit as plain HOST arrays.
+ * Per-cell arrays are UNPADDED (row length n^dim, not the power-of-two `rowlength` of
+ * matrix_free_gpu.cu:483) and hold all cells of all colours in one array; colouring is
+ * done by the library (coloring.cc:8-33 is replaced).                       */
+typedef struct mfgpu_desc {
+  int32_t dim;         /* 2 or 3                                    (bmop.cu:53-57)   */
+  int32_t degree;      /* FE_Q degree p, n = p+1 points per direction (bmop.cu:47-51) */
+  int32_t number_type; /* MFGPU_F64 / MFGPU_F32: type of every `const void*` array and of the vectors */
+  uint32_t flags;
+  uint32_t n_dofs;  /* vector length                              (matrix_free_gpu.cu:494)     */
+  uint32_t n_cells; /* active cells                               (matrix_free_gpu.cu:495)     */
+  const uint32_t *loc2glob;        /* [n_cells * n^dim] lexicographic (x fastest), hanging-node
+                                      entries already substituted   (matrix_free_gpu.cu:287-300) */
+  const uint32_t *constraint_mask; /* [n_cells] or NULL              (hanging_nodes.cuh:23-53)   */
+  const void *JxW;                 /* [n_cells * n^dim]              (matrix_free_gpu.cu:315-322) */
+  const void *inv_jac;             /* UNIFORM_J0: [n_cells]; else [n_cells * n^dim * dim*dim],
+                                      per quadrature point row-major J^-1[d1][d2]
+                                      (matrix_free_gpu.cu:324-338)                                */
+  const void *coefficient;         /* [n_cells * n^dim] values at quadrature points, or NULL to
+                                      evaluate 1/(0.05+2|x|^2) from quadrature_points on the device
+                                      (laplace_operator_gpu.h:191-211, poisson_common.h:149-151)   */
+  const void *quadrature_points;   /* [n_cells * n^dim * dim] (x,y,z per point) or NULL
+                                      (matrix_free_gpu.cu:305-313)                                */
+  const void *shape_values;        /* [n*n], index dof*n + q         (matrix_free_gpu.cu:502-509) */
+  const void *shape_gradients;     /* [n*n], index dof*n + q         (matrix_free_gpu.cu:510-513) */
+  const double *constraint_weights; /* [n*n] row-major W[i][j] or NULL (hanging_nodes.cuh:580-598) */
+  const uint32_t *constrained_dofs; /* ascending list of every constrained DoF, Dirichlet AND
+                                       hanging                        (constraint_handler_gpu.cu:68-95) */
+  uint32_t n_constrained;
+  /* tuning knobs, 0 = library default (no reference counterpart; replaces
+     cells_per_block_shmem, matrix_free_gpu.h:298-315) */
+  uint32_t max_cells_per_batch;
+  uint32_t max_dofs_per_batch;
+} mfgpu_desc;
+
+/* ---- operator (replaces LaplaceOperatorGpu::reinit / vmult / vmult_add / clear) -------- */
+
+/* laplace_operator_gpu.h:120-151 (reinit): copies the description to the device, builds the
+ * batch/colour plan, folds coefficient * J0^2 * JxW.  Uses the current HIP device.           */
+int mfgpu_create(const mfgpu_desc *desc, mfgpu_handle **out);
+
+/* laplace_operator_gpu.h:216-223: dst = A src.  dst, src: device vectors of n_dofs Numbers.
+ * Unlike the reference (const_cast at :293,302) src is never written.  Asynchronous.         */
+int mfgpu_vmult(mfgpu_handle *h, void *dst_dev, const void *src_dev, void *stream);
+
+/* laplace_operator_gpu.h:286-303: dst += A src on free rows, dst_c += src_c on constrained rows. */
+int mfgpu_vmult_add(mfgpu_handle *h, void *dst_dev, const void *src_dev, void *stream);
+
+/* laplace_operator_gpu.h:53-54 m() / n() */
+uint32_t mfgpu_n_dofs(const mfgpu_handle *h);
+
+/* laplace_operator_gpu.h:434-445 */
+size_t mfgpu_memory_consumption(const mfgpu_handle *h);
+
+/* laplace_operator_gpu.h:110-117 (clear) / matrix_free_gpu.cu:566-596 (free) */
+void mfgpu_destroy(mfgpu_handle *h);
+
+const char *mfgpu_last_error(void);
+
+/* Plan statistics (for DESIGN/bench reporting and the CPU-side host-logic tests).
+ * stats[0]=n_batches [1]=n_colors [2]=total batch dofs [3]=max dofs/batch [4]=max cells/batch
+ * [5]=n_orphan_dofs [6]=first-touch stores [7]=read-modify-write adds                         */
+int mfgpu_plan_stats(const mfgpu_handle *h, uint64_t stats[8]);
+
+/* Average device time of the cell-loop kernels of the most recent mfgpu_vmult* calls, measured
+ * with hipEvents on the launch stream when profiling is enabled (bench.py roofline leg).       */
+int mfgpu_profile_enable(mfgpu_handle *h, int on);
+int mfgpu_profile_read(mfgpu_handle *h, double *kernel_ms_total, uint64_t *n_vmults);
+
+/* ---- host-only plan (no GPU needed): same planner the handle uses -------------------------
+ * Lets CPU tests check the batching / colouring / first-touch logic.                         */
+typedef struct mfgpu_plan mfgpu_plan;
+int mfgpu_plan_create(const mfgpu_desc *desc, mfgpu_plan **out);
+void mfgpu_plan_destroy(mfgpu_plan *p);
+/* what: 0 batch_cell_off[n_batches+1] 1 batch_dof_off[n_batches+1] 2 color_batch_off[n_colors+1]
+ *       3 cell_order[n_cells] (plan position -> caller cell) 4 bdofs[total] 5 orphans[n_orphans]
+ * returns element count, *ptr = host pointer valid until mfgpu_plan_destroy                  */
+int64_t mfgpu_plan_array_u32(const mfgpu_plan *p, int what, const uint32_t **ptr);
+int64_t mfgpu_plan_lmap(const mfgpu_plan *p, const uint16_t **ptr);   /* [n_cells*n^dim], plan order */
+int64_t mfgpu_plan_bflags(const mfgpu_plan *p, const uint8_t **ptr);  /* bit0 constrained, bit1 add */
+
+/* ---- GpuVector pieces that are on the path (gpu_vec.h:44,69,84-88,164-172) -------------- */
+int mfgpu_vec_alloc(void **dev, size_t n, int number_type);               /* gpu_vec.cu:166-182, zero-filled */
+int mfgpu_vec_free(void *dev);
+int mfgpu_vec_fill(void *dev, size_t n, int number_type, double value, void *stream); /* vec_init, gpu_vec.cu:281-291 */
+int mfgpu_vec_from_host(void *dev, const void *host, size_t n, int number_type);
+int mfgpu_vec_to_host(void *host, const void *dev, size_t n, int number_type);
+int mfgpu_device_synchronize(void); /* bmop.cu:148 */
+
+/* ---- deal.II stand-in for the setup side (host only) --------------------------------------
+ * Produces what Triangulation + DoFHandler + ConstraintMatrix + FEValues + ShapeInfo hand to
+ * MatrixFreeGpu::reinit, for the meshes bmop uses (bmop_common.h:108-120).                    */
+typedef struct mfgpu_mesh mfgpu_mesh;
+
+/* hyper_cube(lo,hi) subdivided n_per_dir[d] times per direction (generalises refine_global,
+ * poisson_common.h:62-64 + bmop_common.h:119); cells_z_begin/end select a z-slab (last
+ * direction) of cells for the multi-GPU partition: DoFs are renumbered slab-locally.         */
+int mfgpu_mesh_create_uniform(int dim, int degree, const uint32_t *n_per_dir, double lo, double hi,
+                              uint32_t slab_begin, uint32_t slab_end, int number_type,
+                              mfgpu_mesh **out);
+/* bmop_common.h:49-105 pseudo_adaptive_refinement on the cube (ADAPTIVE_GRID), n_ref as in
+ * bmop's argv; octree with 2:1 balance and hanging-node constraints.                          */
+int mfgpu_mesh_create_adaptive(int dim, int degree, int n_ref, int number_type, mfgpu_mesh **out);
+void mfgpu_mesh_destroy(mfgpu_mesh *m);
+/* fills *desc with pointers into the mesh (valid until mfgpu_mesh_destroy) */
+int mfgpu_mesh_desc(const mfgpu_mesh *m, mfgpu_desc *desc);
+/* support-point coordinates of every DoF [n_dofs*dim] (double) */
+int64_t mfgpu_mesh_dof_coords(const mfgpu_mesh *m, const double **ptr);
+/* multi-GPU slabs: local indices of the DoFs on the lower / upper slab interface plane, in the
+ * same (lexicographic) order on both neighbours; which = 0 lower, 1 upper                      */
+int64_t mfgpu_mesh_interface_dofs(const mfgpu_mesh *m, int which, const uint32_t **ptr);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* MFGPU_H */

@@ -1,0 +1,158 @@
+"""CPU-side tests: the C-ABI library loads and exports every declared symbol, the deal.II stand-in
+mesh reproduces the oracle's independent mesh, the planner's invariants hold.  No GPU calls."""
+import os
+import re
+
+import numpy as np
+import pytest
+
+import pymfgpu as mf
+from oracle import mf_oracle as o
+from util import desc_from_oracle, emulate_plan_vmult, oracle_desc_from_mesh
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_library_exports_every_declared_symbol():
+    hdr = open(os.path.join(ROOT, "include", "mfgpu.h")).read()
+    hdr = re.sub(r"/\*.*?\*/", "", hdr, flags=re.S)
+    declared = set(re.findall(r"\b(mfgpu_[a-z0-9_]+)\s*\(", hdr))
+    assert declared == set(mf.SYMBOLS)
+    L = mf.lib()
+    for s in declared:
+        assert hasattr(L, s), s
+
+
+def test_bad_arguments_fail_loudly():
+    d = mf.Desc()
+    with pytest.raises(mf.MfgpuError):
+        mf.Plan(d)
+    od = o.uniform_mesh_desc(2, 2, 2)
+    bad = od.loc2glob.copy()
+    bad[0, 0] = od.n_dofs  # out of range
+    desc, keep = desc_from_oracle(od)
+    desc2, keep2 = mf.make_desc(2, 2, od.n_dofs, bad, od.JxW, od.inv_jac, od.coefficient, od.constrained,
+                                od.shape_values, od.shape_gradients)
+    with pytest.raises(mf.MfgpuError, match="out of range"):
+        mf.Plan(desc2, keep2)
+    with pytest.raises(mf.MfgpuError):
+        mf.Mesh.uniform(2, 9, 2)
+    with pytest.raises(mf.MfgpuError):
+        mf.Mesh.uniform(3, 2, [2, 2, 0])
+
+
+@pytest.mark.parametrize("dim,p,n", [(2, 2, 32), (2, 4, 4), (3, 1, 3), (3, 4, 3), (3, 6, 2), (3, 3, [2, 3, 4])])
+def test_mesh_standin_matches_oracle_mesh(dim, p, n):
+    m = mf.Mesh.uniform(dim, p, n)
+    od = o.uniform_mesh_desc(dim, p, n) if np.isscalar(n) else None
+    a = m.arrays()
+    if od is None:  # anisotropic counts: cube cells need equal h, oracle builder takes a tuple too
+        od = o.uniform_mesh_desc(dim, p, tuple(n), lo=-1.0, hi=-1.0 + 2.0)
+        # h = (hi-lo)/n[0] for both builders
+    assert m.n_dofs == od.n_dofs and m.n_cells == od.n_cells
+    np.testing.assert_array_equal(a["loc2glob"], od.loc2glob)
+    np.testing.assert_array_equal(a["constrained_dofs"], od.constrained)
+    np.testing.assert_allclose(a["JxW"], od.JxW, rtol=1e-13)
+    np.testing.assert_allclose(a["inv_jac"], od.inv_jac, rtol=1e-15)
+    np.testing.assert_allclose(a["shape_values"], od.shape_values, atol=1e-14)
+    np.testing.assert_allclose(a["shape_gradients"], od.shape_gradients, atol=1e-12)
+    np.testing.assert_allclose(a["constraint_weights"], od.weights, atol=1e-14)
+    np.testing.assert_allclose(o.coefficient_value(a["quadrature_points"]), od.coefficient, rtol=1e-13)
+    np.testing.assert_allclose(m.dof_coords(), od.dof_coords, atol=1e-14)
+
+
+def test_c1_sizes():
+    # BASELINE configs[0]: p=2, 2D, 5 global refinements = 32^2 cells, 65^2 dofs, 256 boundary dofs
+    m = mf.Mesh.uniform(2, 2, 32)
+    assert (m.n_cells, m.n_dofs, m.desc.n_constrained) == (1024, 4225, 256)
+
+
+def _plan_invariants(od, plan):
+    nd = od.nd
+    bco, bdo, cbo = plan.batch_cell_off, plan.batch_dof_off, plan.color_batch_off
+    order, bdofs, bflags, lmap = plan.cell_order, plan.bdofs, plan.bflags, plan.lmap
+    nb = len(bco) - 1
+    # every cell exactly once
+    assert sorted(order.tolist()) == list(range(od.n_cells))
+    assert bco[0] == 0 and bco[-1] == od.n_cells and cbo[0] == 0 and cbo[-1] == nb
+    con = np.zeros(od.n_dofs, bool)
+    con[od.constrained] = True
+    touched = np.zeros(od.n_dofs, bool)
+    for c in range(len(cbo) - 1):
+        seen = np.zeros(od.n_dofs, bool)
+        for b in range(cbo[c], cbo[c + 1]):
+            g = bdofs[bdo[b]:bdo[b + 1]]
+            f = bflags[bdo[b]:bdo[b + 1]]
+            assert (np.diff(g.astype(np.int64)) > 0).all()          # ascending, unique
+            assert not seen[g].any()                                 # colour is conflict-free
+            seen[g] = True
+            np.testing.assert_array_equal((f & 1).astype(bool), con[g])
+            np.testing.assert_array_equal((f & 2).astype(bool), touched[g])  # first toucher stores
+            cells = np.arange(bco[b], bco[b + 1])
+            np.testing.assert_array_equal(g[lmap[cells]], od.loc2glob[order[cells]])
+        touched |= seen
+    orph = plan.orphans
+    np.testing.assert_array_equal(np.sort(orph & 0x7fffffff), np.nonzero(~touched)[0])
+    np.testing.assert_array_equal((orph >> 31).astype(bool), con[orph & 0x7fffffff])
+
+
+@pytest.mark.parametrize("dim,p,n,kw", [
+    (2, 2, 8, {}), (3, 2, 4, {}), (3, 4, 3, {}), (3, 4, 6, dict(max_cells_per_batch=27)),
+    (3, 1, 5, dict(max_cells_per_batch=8)), (2, 4, 6, dict(max_cells_per_batch=4, max_dofs_per_batch=60)),
+    (3, 3, 3, dict(max_cells_per_batch=1)),
+])
+def test_plan_invariants_and_dataflow(dim, p, n, kw):
+    od = o.uniform_mesh_desc(dim, p, n)
+    desc, keep = desc_from_oracle(od, **kw)
+    plan = mf.Plan(desc, keep)
+    _plan_invariants(od, plan)
+    rng = np.random.default_rng(0)
+    x, y0 = rng.standard_normal(od.n_dofs), rng.standard_normal(od.n_dofs)
+    ref = o.vmult(od, x)
+    np.testing.assert_allclose(emulate_plan_vmult(od, plan, x), ref, rtol=0, atol=1e-12 * np.abs(ref).max())
+    ref = o.vmult_add(od, y0, x)
+    np.testing.assert_allclose(emulate_plan_vmult(od, plan, x, y0), ref, rtol=0, atol=1e-12 * np.abs(ref).max())
+
+
+def test_plan_orphans_and_ragged_mesh():
+    """dofs no cell touches (as hanging nodes are after substitution) + a disconnected, ragged mesh"""
+    od = o.uniform_mesh_desc(2, 2, 4)
+    keep_cells = np.array([0, 1, 2, 5, 10, 15])  # holes -> orphans, disconnected pieces
+    od2 = o.Desc(2, 2, od.n_dofs, od.loc2glob[keep_cells], od.JxW[keep_cells], od.inv_jac[keep_cells],
+                 od.coefficient[keep_cells], od.constrained)
+    desc, keep = desc_from_oracle(od2, max_cells_per_batch=3)
+    plan = mf.Plan(desc, keep)
+    _plan_invariants(od2, plan)
+    assert len(plan.orphans) > 0
+    x = np.random.default_rng(1).standard_normal(od.n_dofs)
+    ref = o.vmult(od2, x)
+    np.testing.assert_allclose(emulate_plan_vmult(od2, plan, x), ref, atol=1e-12 * np.abs(ref).max())
+
+
+def test_batching_quality_structured():
+    """greedy batching should find compact 3x3x3 blocks on a structured p=4 mesh"""
+    od = o.uniform_mesh_desc(3, 4, 9)
+    desc, keep = desc_from_oracle(od, max_cells_per_batch=27)
+    plan = mf.Plan(desc, keep)
+    nb = len(plan.batch_cell_off) - 1
+    assert nb == 27, nb
+    assert np.diff(plan.batch_dof_off).max() == 13 ** 3
+    assert len(plan.color_batch_off) - 1 == 8
+
+
+def test_slab_meshes_tile_the_global_mesh():
+    """multi-GPU partition: z-slabs with consistent interface planes"""
+    dim, p, n = 3, 2, 4
+    full = mf.Mesh.uniform(dim, p, n)
+    lo_m = mf.Mesh.uniform(dim, p, n, slab=(0, 2))
+    hi_m = mf.Mesh.uniform(dim, p, n, slab=(2, 4))
+    assert lo_m.n_cells + hi_m.n_cells == full.n_cells
+    i_up, i_lo = lo_m.interface_dofs(1), hi_m.interface_dofs(0)
+    assert len(i_up) == len(i_lo) == (p * n + 1) ** 2
+    assert len(lo_m.interface_dofs(0)) == 0 and len(hi_m.interface_dofs(1)) == 0
+    np.testing.assert_allclose(lo_m.dof_coords()[i_up], hi_m.dof_coords()[i_lo], atol=1e-15)
+    # interface dofs that are on the global boundary are constrained on both sides
+    c_lo = np.isin(i_up, lo_m.arrays()["constrained_dofs"])
+    c_hi = np.isin(i_lo, hi_m.arrays()["constrained_dofs"])
+    np.testing.assert_array_equal(c_lo, c_hi)
+    assert c_lo.sum() == (p * n + 1) ** 2 - (p * n - 1) ** 2

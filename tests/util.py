@@ -1,0 +1,62 @@
+"""Shared helpers for the tests (host side only)."""
+import numpy as np
+
+import pymfgpu as mf
+from oracle import mf_oracle as o
+
+
+def oracle_desc_from_mesh(mesh: "mf.Mesh", dtype=None) -> o.Desc:
+    """Oracle description built from the SAME plain arrays the product hands to mfgpu_create."""
+    a = mesh.arrays()
+    d = mesh.desc
+    dt = mf.np_dtype(d.number_type) if dtype is None else dtype
+    coef = o.coefficient_value(a["quadrature_points"].astype(np.float64))
+    return o.Desc(d.dim, d.degree, d.n_dofs, a["loc2glob"], a["JxW"], a["inv_jac"], coef,
+                  a["constrained_dofs"], a["constraint_mask"], dt, a["shape_values"], a["shape_gradients"],
+                  a["constraint_weights"], mesh.dof_coords())
+
+
+def desc_from_oracle(od: o.Desc, number_type=mf.F64, **kw):
+    """C-ABI description from an oracle Desc (independent oracle-side mesh -> product)."""
+    return mf.make_desc(od.dim, od.degree, od.n_dofs, od.loc2glob, od.JxW, od.inv_jac, od.coefficient,
+                        od.constrained, od.shape_values, od.shape_gradients, number_type,
+                        od.constraint_mask, od.weights if od.constraint_mask is not None else None, **kw)
+
+
+def emulate_plan_vmult(od: o.Desc, plan: "mf.Plan", src, dst_in=None):
+    """numpy emulation of the kernel's DATA FLOW driven by the plan arrays (gather through
+    bdofs/lmap, per-batch accumulation, first-touch store / add, orphans), with the oracle as the
+    cell kernel.  Checks the planner, not the HIP code."""
+    add = dst_in is not None
+    dst = np.full(od.n_dofs, np.nan) if not add else np.array(dst_in, dtype=np.float64)
+    bco, bdo, order = plan.batch_cell_off, plan.batch_dof_off, plan.cell_order
+    bdofs, bflags, lmap = plan.bdofs, plan.bflags, plan.lmap
+    # permuted oracle desc (plan cell order)
+    pd = o.Desc(od.dim, od.degree, od.n_dofs, od.loc2glob[order], od.JxW[order], od.inv_jac[order],
+                od.coefficient[order], od.constrained,
+                None if od.constraint_mask is None else od.constraint_mask[order], od.dtype,
+                od.shape_values, od.shape_gradients, od.weights)
+    for b in range(len(bco) - 1):
+        g = bdofs[bdo[b]:bdo[b + 1]]
+        f = bflags[bdo[b]:bdo[b + 1]]
+        usrc = np.where(f & 1, 0.0, src[g])
+        acc = np.zeros(len(g))
+        cells = np.arange(bco[b], bco[b + 1])
+        sub = o.Desc(pd.dim, pd.degree, pd.n_dofs, pd.loc2glob[cells], pd.JxW[cells], pd.inv_jac[cells],
+                     pd.coefficient[cells], pd.constrained,
+                     None if pd.constraint_mask is None else pd.constraint_mask[cells], pd.dtype,
+                     pd.shape_values, pd.shape_gradients, pd.weights)
+        loc = o.cell_apply(sub, usrc[lmap[cells]])
+        np.add.at(acc, lmap[cells].reshape(-1), loc.reshape(-1))
+        con, addf = (f & 1).astype(bool), (f & 2).astype(bool)
+        first_con = con & ~addf
+        dst[g[first_con]] = (dst[g[first_con]] if add else 0.0) + src[g[first_con]]
+        free_add = ~con & (addf | add)
+        dst[g[free_add]] += acc[free_add]
+        free_store = ~con & ~(addf | add)
+        dst[g[free_store]] = acc[free_store]
+    for oo in plan.orphans:
+        g = int(oo & 0x7fffffff)
+        s = src[g] if (oo >> 31) else 0.0
+        dst[g] = (dst[g] if add else 0.0) + s
+    return dst
