@@ -1,0 +1,214 @@
+#!/usr/bin/env python3
+"""bench.py -- DoFs/s of consecutive Laplace vmult applies (the reference's bmop protocol).
+
+One "step" = one operator apply  dst = A src  over the whole mesh, preceded by the pointer swap of
+bmop.cu:142-146 (dst = 0.1 initially; K x { swap(dst,src); vmult(dst,src) }).  Workload at N = 1:
+BASELINE.json configs[1]: DEGREE_FE=4, DIMENSION=3, uniform cube, n = 54 cells per direction
+(157 464 cells, 217^3 = 10 218 313 DoFs), double.  For N > 1 the global cube has
+n(N) = round(54 N^(1/3)) cells per direction (configs[3]: N = 8 -> 108^3 cells, 81 182 737 DoFs) and is
+sharded by z-slabs, one process per GPU, interface-plane sums over RCCL (weak scaling).
+
+Prints ONE JSON line on rank 0.  Inputs are resident in HBM when the timed region starts.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+for _p in (ROOT, os.path.join(ROOT, "dealii-cuda_amd")):
+    if _p not in sys.path:
+        sys.path.insert(0, _p)
+
+import torch  # noqa: E402  (FIRST: libmfgpu.so must bind to the HIP runtime torch already loaded)
+import torch.distributed as dist  # noqa: E402
+import numpy as np  # noqa: E402
+
+import pymfgpu as mf  # noqa: E402
+from pymfgpu.parallel import SlabExchange, slab_ranges  # noqa: E402
+
+HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
+
+
+def algorithmic_bytes(n_dofs, n_cells, nd, s):
+    """src read once, dst written once, one coefficient value and one 32-bit dof
+    index per local dof / quadrature point."""
+    return 2 * s * n_dofs + n_cells * nd * (s + 4)
+
+
+def cpu_baseline(args, budget_s=12.0):
+    """oracle/cpu_ref.c (a port, not the reference: the reference CPU path needs deal.II) on the host
+    cores, same mesh and protocol, bounded sample: as many vmults as fit in ~budget_s (>= 2)."""
+    from oracle import cpu_ref
+    from oracle import mf_oracle as o
+
+    n = args.cpu_cells
+    mesh = mf.Mesh.uniform(3, args.degree, n)
+    a = mesh.arrays()
+    od = o.Desc(3, args.degree, mesh.n_dofs, a["loc2glob"], a["JxW"], a["inv_jac"],
+                o.coefficient_value(a["quadrature_points"]), a["constrained_dofs"], None, np.float64,
+                a["shape_values"], a["shape_gradients"])
+    ref = cpu_ref.CpuRef(od, cpu_ref.structured_cell_colors([n] * 3))
+    x = np.full(mesh.n_dofs, 0.1)
+    ref.vmult(x)  # warm-up (page faults, thread pool)
+    t0 = time.perf_counter()
+    k = 0
+    while True:
+        x = ref.vmult(x)
+        k += 1
+        t = time.perf_counter() - t0
+        if (k >= 2 and t > budget_s) or k >= 100:
+            break
+    return {"value": mesh.n_dofs * k / t, "unit": "DoFs/s", "cores": int(ref.threads), "kind": "port",
+            "sample": f"{k} vmult of p={args.degree} 3D uniform n={n} ({mesh.n_dofs} DoFs), oracle/cpu_ref.c, "
+                      f"OpenMP {ref.threads} threads, {t:.1f} s"}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=100)
+    ap.add_argument("--warmup", type=int, default=10)
+    ap.add_argument("--degree", type=int, default=4)
+    ap.add_argument("--cells", type=int, default=54, help="cells per direction at N=1")
+    ap.add_argument("--cpu-cells", type=int, default=32, help="cells per direction of the CPU sample")
+    ap.add_argument("--float", action="store_true", help="BMOP_USE_FLOATS")
+    ap.add_argument("--mode", default="pair", choices=["pair", "allreduce"])
+    ap.add_argument("--no-cpu", action="store_true")
+    ap.add_argument("--batch-cells", type=int, default=0)
+    ap.add_argument("--batch-dofs", type=int, default=0)
+    ap.add_argument("--colored", action="store_true", help="coloured-scatter mode instead of two-pass")
+    args = ap.parse_args()
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run")
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a GPU (the HIP path has no CPU fallback)")
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+
+    nt = mf.F32 if args.float else mf.F64
+    tdt = torch.float32 if args.float else torch.float64
+    s = 4 if args.float else 8
+    p = args.degree
+    n_glob = int(round(args.cells * world ** (1.0 / 3.0)))
+    zb, ze = slab_ranges(n_glob, world)[rank]
+    mesh = mf.Mesh.uniform(3, p, n_glob, slab=(zb, ze), number_type=nt)
+    mesh.desc.max_cells_per_batch = args.batch_cells
+    mesh.desc.max_dofs_per_batch = args.batch_dofs
+    if args.colored:
+        mesh.desc.flags |= mf.COLORED_SCATTER
+    op = mf.Operator(mesh.desc, mesh)
+    stats = op.plan_stats()
+    N_loc = mesh.n_dofs
+    nd = (p + 1) ** 3
+    n_dofs_glob = (p * n_glob + 1) ** 3
+    n_cells_glob = n_glob ** 3
+
+    dst = torch.full((N_loc,), 0.1, device=dev, dtype=tdt)  # bmop.cu:140
+    src = torch.zeros(N_loc, device=dev, dtype=tdt)
+    exch = SlabExchange(mesh, rank, world, dev, tdt, args.mode) if world > 1 else None
+    stream = torch.cuda.current_stream().cuda_stream
+
+    def step():
+        nonlocal dst, src
+        dst, src = src, dst  # GpuVector::swap
+        op.vmult(dst, src, stream)
+        if exch is not None:
+            exch.exchange_add(dst)
+
+    def renorm():
+        # the un-normalised protocol overflows double after ~100 applies (values grow by ||A|| per
+        # apply); rescale OUTSIDE the timed region so warm-up + profile legs never hit inf
+        nonlocal dst
+        m = dst.abs().max()
+        if world > 1:
+            dist.all_reduce(m, op=dist.ReduceOp.MAX)
+        dst.mul_(0.1 / m)
+
+    for _ in range(args.warmup):
+        step()
+    renorm()
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t = time.perf_counter() - t0
+    tt = torch.tensor([t], device=dev, dtype=torch.float64)
+    if world > 1:
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+    t = float(tt.item())
+    finite = bool(torch.isfinite(dst).all().item())
+
+    # ---- roofline leg: per-launch HIP-event timing of the cell-loop kernel on the launch stream
+    renorm()
+    op.profile_enable(True)
+    n_prof = min(args.steps, 20)
+    for _ in range(n_prof):
+        dst, src = src, dst
+        op.vmult(dst, src, stream)
+    k_ms, n_v = op.profile_read()
+    op.profile_enable(False)
+    launches = n_v * stats["n_launches"]
+    b_alg_loc = algorithmic_bytes(N_loc, mesh.n_cells, nd, s)
+    achieved = b_alg_loc * n_v / (k_ms * 1e-3) / 1e9  # GB/s, == (B_alg/launch) / (avg launch duration)
+    traffic = None
+    tj = os.path.join(ROOT, "profiles", "traffic_latest.json")
+    if os.path.exists(tj):
+        try:
+            tr = json.load(open(tj))
+            if tr.get("workload") == f"p{p}_3d_n{n_glob}_{'f32' if args.float else 'f64'}" and world == 1:
+                traffic = tr["hbm_bytes_per_launch"]
+        except Exception:
+            traffic = None
+
+    out = {
+        "metric": "DoFs/s on 100x Laplace vmult (bmop), p=4 3D uniform",
+        "value": n_dofs_glob * args.steps / t,
+        "unit": "DoFs/s",
+        "n_gpus": world,
+        "steps": args.steps,
+        "warmup": args.warmup,
+        "ms_per_step": 1e3 * t / args.steps,
+        "higher_is_better": True,
+        "scaling": "weak",
+        "vs_baseline": None,
+        "dtype": "f32" if args.float else "f64",
+        "data": "synthetic",
+        "config": {"workload": f"bmop: DEGREE_FE={p}, DIMENSION=3, MATRIX_FREE_UNIFORM_MESH, hyper_cube(-1,1), "
+                               f"{n_glob}^3 cells, {n_dofs_glob} DoFs, {world} z-slab(s)",
+                   "cells_per_dir": n_glob, "n_dofs": n_dofs_glob, "n_cells": n_cells_glob,
+                   "parallelism": f"slab{world}" + (f"/{args.mode}" if world > 1 else ""),
+                   "plan": stats, "finite": finite},
+        "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                     "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
+                     "kernel": "apply_batches", "launches": launches,
+                     "avg_launch_us": 1e3 * k_ms / max(launches, 1),
+                     "alg_bytes_per_launch": b_alg_loc / stats["n_launches"],
+                     "kernel_ms_per_vmult": k_ms / max(n_v, 1)},
+    }
+    if rank == 0 and world == 1 and not args.no_cpu:
+        out["cpu_baseline"] = cpu_baseline(args)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+    if rank == 0:
+        print(json.dumps(out))
+
+
+if __name__ == "__main__":
+    main()

@@ -2,6 +2,7 @@
 #include <hip/hip_runtime.h>
 
 #include <cmath>
+#include <cstdlib>
 #include <cstring>
 #include <string>
 #include <vector>
@@ -31,6 +32,12 @@ struct mfgpu_handle {
   void *d_coef = nullptr;
   uint32_t *d_cmask = nullptr, *d_orphans = nullptr;
   void *d_hnw = nullptr;
+  // two-pass mode
+  bool twopass = true;
+  uint32_t *d_batch_nint = nullptr, *d_halo_off = nullptr, *d_sdofs = nullptr, *d_s_off = nullptr,
+           *d_s_idx = nullptr;
+  void *d_halo = nullptr;
+  unsigned long long *d_stamps = nullptr;  // diagnostic build only
   size_t lds = 0, device_bytes = 0;
   // profiling
   bool prof = false;
@@ -95,6 +102,19 @@ int create_typed(mfgpu_handle *h, const mfgpu_desc &d) {
   if ((rc = dev_upload(&h->d_bflags, P.bflags.data(), P.bflags.size(), acct))) return rc;
   if ((rc = dev_upload(&h->d_lmap, P.lmap.data(), P.lmap.size() * 2, acct))) return rc;
   if ((rc = dev_upload(&h->d_orphans, P.orphans.data(), P.orphans.size() * 4, acct))) return rc;
+  if (h->twopass) {
+    if ((rc = dev_upload(&h->d_batch_nint, P.batch_nint.data(), P.batch_nint.size() * 4, acct))) return rc;
+    if ((rc = dev_upload(&h->d_halo_off, P.halo_off.data(), P.halo_off.size() * 4, acct))) return rc;
+    if ((rc = dev_upload(&h->d_sdofs, P.sdofs.data(), P.sdofs.size() * 4, acct))) return rc;
+    if ((rc = dev_upload(&h->d_s_off, P.s_off.data(), P.s_off.size() * 4, acct))) return rc;
+    if ((rc = dev_upload(&h->d_s_idx, P.s_idx.data(), P.s_idx.size() * 4, acct))) return rc;
+    const size_t hb = (size_t)P.halo_off.back() * sizeof(T);
+    if (hb) {
+      HIP_TRY(hipMalloc(&h->d_halo, hb));
+      HIP_TRY(hipMemset(h->d_halo, 0, hb));
+      acct += hb;
+    }
+  }
   if (h->hn) {
     std::vector<uint32_t> cm(ncell);
     for (size_t i = 0; i < ncell; ++i) cm[i] = d.constraint_mask[P.cell_order[i]];
@@ -161,14 +181,24 @@ int vmult_typed(mfgpu_handle *h, void *dst, const void *src, hipStream_t st, int
   a.coef = (const T *)h->d_coef;
   a.cmask = h->d_cmask;
   a.hn_weights = (const T *)h->d_hnw;
+  a.batch_nint = h->d_batch_nint;
+  a.halo_off = h->d_halo_off;
+  a.halo = (T *)h->d_halo;
   a.dst = (T *)dst;
   a.src = (const T *)src;
   a.nb_max = P.max_batch_dofs;
   a.add = add;
-  const size_t ncol = P.color_batch_off.size() - 1;
+  a.stamps = h->d_stamps;
+  a.dbg = 0;
+#ifdef MFGPU_STAMPS
+  if (const char *e = getenv("MFGPU_DBG")) a.dbg = atoi(e);
+#endif
+  // two-pass mode: ONE sweep over all batches (no inter-batch dependency), then the shared-dof sums;
+  // coloured mode: one launch per batch colour (first toucher stores, later colours add)
+  const size_t ncol = h->twopass ? 1 : P.color_batch_off.size() - 1;
   for (size_t c = 0; c < ncol; ++c) {
-    a.batch0 = P.color_batch_off[c];
-    const uint32_t nbat = P.color_batch_off[c + 1] - a.batch0;
+    a.batch0 = h->twopass ? 0u : P.color_batch_off[c];
+    const uint32_t nbat = (h->twopass ? (uint32_t)(P.batch_cell_off.size() - 1) : P.color_batch_off[c + 1]) - a.batch0;
     if (nbat == 0) continue;
     if (h->prof) {
       if (h->ev_used + 2 > h->ev.size()) {
@@ -180,12 +210,15 @@ int vmult_typed(mfgpu_handle *h, void *dst, const void *src, hipStream_t st, int
       }
       HIP_TRY(hipEventRecord(h->ev[h->ev_used], st));
     }
-    HIP_TRY(apply_launch<T>(P.dim, P.n, a, h->S.data(), h->Dt.data(), h->hn, nbat, st));
+    HIP_TRY(apply_launch<T>(P.dim, P.n, a, h->S.data(), h->Dt.data(), h->hn, h->twopass, nbat, st));
     if (h->prof) {
       HIP_TRY(hipEventRecord(h->ev[h->ev_used + 1], st));
       h->ev_used += 2;
     }
   }
+  if (h->twopass)
+    HIP_TRY(reduce_launch<T>((T *)dst, (const T *)src, (const T *)h->d_halo, h->d_sdofs, h->d_s_off, h->d_s_idx,
+                             (uint32_t)P.sdofs.size(), add, st));
   HIP_TRY(orphan_launch<T>((T *)dst, (const T *)src, h->d_orphans, (uint32_t)P.orphans.size(), add, st));
   if (h->prof) h->prof_vmults++;
   return 0;
@@ -231,6 +264,7 @@ int mfgpu_create(const mfgpu_desc *desc, mfgpu_handle **out) {
   h->nd = h->plan.nd;
   h->number_type = d.number_type;
   h->hn = hn;
+  h->twopass = !(d.flags & MFGPU_COLORED_SCATTER);
   const int nn = h->n * h->n;
   std::vector<double> sv(nn), sg(nn);
   for (int i = 0; i < nn; ++i) {
@@ -259,6 +293,13 @@ void mfgpu_destroy(mfgpu_handle *h) {
   hipFree(h->d_cmask);
   hipFree(h->d_orphans);
   hipFree(h->d_hnw);
+  hipFree(h->d_batch_nint);
+  hipFree(h->d_halo_off);
+  hipFree(h->d_sdofs);
+  hipFree(h->d_s_off);
+  hipFree(h->d_s_idx);
+  hipFree(h->d_halo);
+  hipFree(h->d_stamps);
   for (hipEvent_t e : h->ev) hipEventDestroy(e);
   delete h;
 }
@@ -304,6 +345,11 @@ int mfgpu_plan_stats(const mfgpu_handle *h, uint64_t s[8]) {
   s[5] = P.orphans.size();
   s[6] = P.n_first;
   s[7] = P.n_add;
+  if (h->twopass) {  // two-pass mode reports shared dofs / halo partial sums instead
+    s[1] = 1;
+    s[6] = P.sdofs.size();
+    s[7] = P.halo_off.back();
+  }
   return 0;
 }
 
@@ -329,6 +375,24 @@ int mfgpu_profile_read(mfgpu_handle *h, double *ms, uint64_t *nv) {
   *nv = h->prof_vmults;
   return 0;
 }
+
+#ifdef MFGPU_STAMPS
+// diagnostic build only: allocate / read the per-workgroup phase stamps (16 u64 per batch)
+int mfgpu_debug_stamps(mfgpu_handle *h, unsigned long long *out, size_t n_batches) {
+  if (!h) return MFGPU_EINVAL;
+  const size_t nbt = h->plan.batch_cell_off.size() - 1;
+  if (!h->d_stamps) {
+    HIP_TRY(hipMalloc((void **)&h->d_stamps, nbt * 16 * sizeof(unsigned long long)));
+    HIP_TRY(hipMemset(h->d_stamps, 0, nbt * 16 * sizeof(unsigned long long)));
+    return 0;
+  }
+  if (out && n_batches == nbt) {
+    HIP_TRY(hipDeviceSynchronize());
+    HIP_TRY(hipMemcpy(out, h->d_stamps, nbt * 16 * sizeof(unsigned long long), hipMemcpyDeviceToHost));
+  }
+  return 0;
+}
+#endif
 
 // ---- GpuVector pieces -----------------------------------------------------------------------
 

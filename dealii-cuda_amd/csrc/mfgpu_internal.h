@@ -32,10 +32,18 @@ struct Plan {
   std::vector<uint32_t> batch_cell_off;   // [n_batches+1] into plan positions
   std::vector<uint32_t> batch_dof_off;    // [n_batches+1] into bdofs
   std::vector<uint32_t> color_batch_off;  // [n_colors+1]
-  std::vector<uint32_t> bdofs;            // ascending global dof ids per batch
+  std::vector<uint32_t> bdofs;            // global dof ids per batch [interior asc | shared asc]; bit 31 = constrained
   std::vector<uint8_t> bflags;            // per bdofs entry
   std::vector<uint16_t> lmap;             // [n_cells*nd] plan order: local dof -> batch-local id
   std::vector<uint32_t> orphans;          // dofs touched by no cell; bit 31 set = constrained
+  // two-pass ("owner gathers") mode: per batch the dofs are ordered [interior | shared]; interior
+  // dofs (touched by this batch only) are written straight to dst, partial sums of shared dofs go
+  // to a halo buffer slot and are summed per dof by a second kernel in fixed batch order
+  std::vector<uint32_t> batch_nint;       // [n_batches] number of interior dofs of the batch
+  std::vector<uint32_t> halo_off;         // [n_batches+1] first halo slot of the batch's shared dofs
+  std::vector<uint32_t> sdofs;            // [n_shared] ascending global ids; bit 31 = constrained
+  std::vector<uint32_t> s_off;            // [n_shared+1] CSR into s_idx
+  std::vector<uint32_t> s_idx;            // halo slots of the partial sums, ascending batch order
   uint32_t max_batch_dofs = 0, max_batch_cells = 0;
   uint64_t n_first = 0, n_add = 0;
 };

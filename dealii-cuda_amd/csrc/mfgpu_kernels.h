@@ -18,11 +18,16 @@ struct ApplyArgs {
   const T *coef;          // folded a*J0^2*JxW, plan cell order
   const uint32_t *cmask;  // plan cell order, or nullptr
   const T *hn_weights;    // [n*n] W[i*n+j] (device), or nullptr
+  const uint32_t *batch_nint;  // two-pass mode: interior dofs per batch
+  const uint32_t *halo_off;    // two-pass mode: first halo slot per batch
+  T *halo;                     // two-pass mode: partial sums of shared dofs
   T *dst;
   const T *src;
   uint32_t batch0;  // first batch of this launch (colour)
   uint32_t nb_max;  // LDS layout: max dofs per batch
   int add;          // vmult_add semantics
+  unsigned long long *stamps;  // diagnostic build only (MFGPU_STAMPS), else nullptr
+  int dbg;                     // diagnostic build only: ablation bits (1 cells, 2 gather, 4 scatter, 8 prefetch)
 };
 
 // 1D tables, passed by value as kernel arguments (=> scalar registers).
@@ -38,7 +43,10 @@ template <typename T>
 hipError_t apply_configure(int dim, int n, size_t lds);
 template <typename T>
 hipError_t apply_launch(int dim, int n, const ApplyArgs<T> &a, const double *S, const double *Dt,
-                        bool hn, uint32_t nbatches, hipStream_t st);
+                        bool hn, bool twopass, uint32_t nbatches, hipStream_t st);
+template <typename T>
+hipError_t reduce_launch(T *dst, const T *src, const T *halo, const uint32_t *sdofs, const uint32_t *s_off,
+                         const uint32_t *s_idx, uint32_t ns, int add, hipStream_t st);
 template <typename T>
 hipError_t orphan_launch(T *dst, const T *src, const uint32_t *orph, uint32_t n, int add, hipStream_t st);
 template <typename T>

@@ -122,67 +122,158 @@ __device__ __forceinline__ void lds_add(T *p, T v) {
   unsafeAtomicAdd(p, v);  // ds_add_f64 / ds_add_f32: no CAS loop on gfx950
 }
 
-template <int dim, int n, typename T, bool HN>
+// Diagnostic build only (-DMFGPU_STAMPS, lib/libmfgpu_diag.so): lane 0 of every workgroup records
+// s_memtime at phase boundaries into a buffer no kernel reads.  The product build has no stamps.
+#ifdef MFGPU_STAMPS
+#define STAMP(k)                                                                          \
+  do {                                                                                    \
+    if (A.stamps && threadIdx.x == 0) {                                                   \
+      unsigned long long t_;                                                              \
+      asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_)::"memory");           \
+      A.stamps[(size_t)(A.batch0 + blockIdx.x) * 16 + (k)] = t_;                          \
+    }                                                                                     \
+  } while (0)
+#define DBG(bit) (A.dbg & (bit))
+#else
+#define STAMP(k)
+#define DBG(bit) 0
+#endif
+
+constexpr int kGU = 9;  // gather/scatter unroll: kGU*kBlock batch dofs per pass, all loads in flight
+
+// Per-chunk global streams of one thread: folded coefficient in the three pencil layouts and the
+// local->batch index map in the first (x) and last (z / y in 2D) layout.  They are issued one phase
+// before use so that their latency hides behind the contraction stages.
+template <int n, typename T>
+struct ChunkLoads {
+  T cz[n], cy[n], cx[n];
+  uint16_t ix[n], iz[n];
+};
+
+template <int dim, int n, typename T, bool HN, bool TWOPASS>
 __global__ void __launch_bounds__(kBlock)
 apply_batches(const ApplyArgs<T> A, const Tables<T, n> tab) {
   constexpr int nd = (dim == 3) ? n * n * n : n * n;
   constexpr int P = nd / n;          // pencils per cell
   constexpr int CH = kBlock / P;     // cells per chunk
   constexpr int n2 = n * n;
+  constexpr int CHND = CH * nd;
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
   T *usrc = reinterpret_cast<T *>(smem_raw);
   T *acc = usrc + A.nb_max;
   T *Wb = acc + A.nb_max;
-  T *Rb = Wb + CH * nd;
-  T *Wl = Rb + CH * nd;  // hanging-node weights (HN only), broadcast reads
+  T *Rb = Wb + CHND;
+  T *Wl = Rb + CHND;     // hanging-node weights (HN only), broadcast reads
 
   const int tid = threadIdx.x;
   const uint32_t b = A.batch0 + blockIdx.x;
   const uint32_t c0 = A.batch_cell_off[b], c1 = A.batch_cell_off[b + 1];
   const uint32_t d0 = A.batch_dof_off[b];
   const int nb = (int)(A.batch_dof_off[b + 1] - d0);
+  const int ncell = (int)(c1 - c0);
 
-  if (HN) {
-    for (int t = tid; t < n * n; t += kBlock) Wl[t] = A.hn_weights[t];
-  }
-  // ---- 1. gather (read_dof_values, fee_gpu.cuh:323-331, once per batch dof)
-  for (int t = tid; t < nb; t += kBlock) {
-    const uint32_t g = A.bdofs[d0 + t];
-    const uint8_t f = A.bflags[d0 + t];
-    usrc[t] = (f & kFlagConstrained) ? T(0) : A.src[g];
-    acc[t] = T(0);
-  }
-  __syncthreads();
-
-  // ---- 2. cells
   const int lc = tid / P;
   const int pen = tid - lc * P;
   const int pa = (dim == 3) ? pen % n : pen;
   const int pb = (dim == 3) ? pen / n : 0;
-  const int ncell = (int)(c1 - c0);
+  const int bx = (dim == 3) ? n * pa + n2 * pb : n * pa;  // x-pencil, stride 1
+  const int by = (dim == 3) ? pa + n2 * pb : pa;          // y-pencil, stride n
+  const int bz = pa + n * pb;                             // z-pencil, stride n2 (3D only)
+  constexpr int sl = (dim == 3) ? n2 : n;                 // stride of the last direction
+  const int bl = (dim == 3) ? bz : by;                    // pencil base of the last direction
+
+  ChunkLoads<n, T> L;
+  auto load_idx = [&](int base) {
+    const uint16_t *lm = A.lmap + ((size_t)c0 + base + lc) * nd;
+#pragma unroll
+    for (int i = 0; i < n; ++i) {
+      L.ix[i] = lm[bx + i];
+      L.iz[i] = lm[bl + i * sl];
+    }
+  };
+  auto load_coef = [&](int base) {
+    const T *cf = A.coef + ((size_t)c0 + base + lc) * nd;
+#pragma unroll
+    for (int i = 0; i < n; ++i) {
+      if (dim == 3) L.cz[i] = cf[bz + i * n2];
+      L.cy[i] = cf[by + i * n];
+      L.cx[i] = cf[bx + i];
+    }
+  };
+  STAMP(0);
+  const bool act0 = (tid < CH * P) && (lc < ncell);
+  if (act0 && !DBG(8)) {
+    load_idx(0);
+    load_coef(0);  // in flight during the gather
+  }
+  if (HN) {
+    for (int t = tid; t < n2; t += kBlock) Wl[t] = A.hn_weights[t];
+  }
+  // ---- 1. gather (read_dof_values, fee_gpu.cuh:323-331, once per batch dof).  All loads are
+  // unconditional on clamped indices: predicated loads become one branch + s_waitcnt vmcnt(0) EACH
+  // (18 serialized memory round trips in an earlier version of this loop).
+  // bdofs bit 31 = constrained row: reads as 0 (constraint_handler_gpu.cu:258-259) and, if this batch
+  // owns the row, dst = src is written here (identity rows, constraint_handler_gpu.cu:286).
+  const int nint = TWOPASS ? (int)A.batch_nint[b] : 0;
+  for (int t0 = 0; t0 < nb; t0 += kGU * kBlock) {
+    uint32_t g[kGU];
+    uint8_t f[kGU];
+    T sv[kGU];
+#pragma unroll
+    for (int j = 0; j < kGU; ++j) {
+      const int t = t0 + tid + j * kBlock;
+      const int tc = t < nb ? t : nb - 1;
+      g[j] = A.bdofs[d0 + tc];
+      if (!TWOPASS) f[j] = A.bflags[d0 + tc];
+    }
+#pragma unroll
+    for (int j = 0; j < kGU; ++j) sv[j] = DBG(2) ? T(0) : A.src[g[j] & 0x7fffffffu];
+#pragma unroll
+    for (int j = 0; j < kGU; ++j) {
+      const int t = t0 + tid + j * kBlock;
+      const bool con = (g[j] >> 31) != 0;
+      if (t < nb) {
+        usrc[t] = con ? T(0) : sv[j];
+        acc[t] = T(0);
+        const bool owner = TWOPASS ? (t < nint) : !(f[j] & kFlagAdd);
+        if (con && owner) {
+          T *d = A.dst + (g[j] & 0x7fffffffu);
+          *d = A.add ? *d + sv[j] : sv[j];
+        }
+      }
+    }
+  }
+  STAMP(2);
+  __syncthreads();
+  STAMP(3);
+
+  // ---- 2. cells
   T *Wc = Wb + lc * nd;
   T *Rc = Rb + lc * nd;
-  for (int base = 0; base < ncell; base += CH) {
+  for (int base = 0; base < (DBG(1) ? 0 : ncell); base += CH) {
     const bool act = (tid < CH * P) && (base + lc < ncell);
-    const size_t cell = (size_t)c0 + base + lc;
-    const uint16_t *lm = A.lmap + cell * nd;
-    const T *cf = A.coef + cell * nd;
+    const int nxt = base + CH;
+    const bool act_next = (tid < CH * P) && (nxt + lc < ncell);
     unsigned mask = 0;
     bool any_mask = false;
     if (HN) {
-      if (act) mask = A.cmask[cell];
+      if (act) mask = A.cmask[(size_t)c0 + base + lc];
       any_mask = __syncthreads_or(mask != 0);
     }
     T u[n], v[n], w[n], g[n], r[n];
+    uint16_t ix[n], iz[n];
+    if (act) {
+#pragma unroll
+      for (int i = 0; i < n; ++i) {
+        ix[i] = L.ix[i];
+        iz[i] = L.iz[i];
+      }
+#pragma unroll
+      for (int i = 0; i < n; ++i) u[i] = usrc[ix[i]];
+    }
+    if (act_next) load_idx(nxt);  // index map of the next chunk: needed right at its start
 
     if (dim == 3) {
-      const int bx = n * pa + n2 * pb;  // x-pencil (y=pa, z=pb), stride 1
-      const int by = pa + n2 * pb;      // y-pencil (x=pa, z=pb), stride n
-      const int bz = pa + n * pb;       // z-pencil (x=pa, y=pb), stride n2
-      if (act) {
-#pragma unroll
-        for (int i = 0; i < n; ++i) u[i] = usrc[lm[bx + i]];
-      }
       if (HN && any_mask) {
         // resolve_hanging_nodes_shmem<NOTRANSPOSE>: x, then y, then z (hanging_nodes.cuh:767-777)
         bool type;
@@ -224,7 +315,7 @@ apply_batches(const ApplyArgs<T> A, const Tables<T, n> tab) {
         mvt<n, 1>(tab.S, u, w);
         mv<n, -1>(tab.Dt, w, g);
 #pragma unroll
-        for (int s = 0; s < n; ++s) g[s] *= cf[bz + s * n2];
+        for (int s = 0; s < n; ++s) g[s] *= L.cz[s];
         mvt<n, -1>(tab.Dt, g, r);
         lds_store<n>(Wc + bz, n2, w);
         lds_store<n>(Rc + bz, n2, r);
@@ -235,7 +326,7 @@ apply_batches(const ApplyArgs<T> A, const Tables<T, n> tab) {
         lds_load<n>(Wc + by, n, w);
         mv<n, -1>(tab.Dt, w, g);
 #pragma unroll
-        for (int s = 0; s < n; ++s) g[s] *= cf[by + s * n];
+        for (int s = 0; s < n; ++s) g[s] *= L.cy[s];
         mvt<n, -1>(tab.Dt, g, r);
         lds_load<n>(Rc + by, n, v);
 #pragma unroll
@@ -248,7 +339,7 @@ apply_batches(const ApplyArgs<T> A, const Tables<T, n> tab) {
         lds_load<n>(Wc + bx, 1, w);
         mv<n, -1>(tab.Dt, w, g);
 #pragma unroll
-        for (int s = 0; s < n; ++s) g[s] *= cf[bx + s];
+        for (int s = 0; s < n; ++s) g[s] *= L.cx[s];
         mvt<n, -1>(tab.Dt, g, r);
         lds_load<n>(Rc + bx, 1, v);
 #pragma unroll
@@ -256,6 +347,7 @@ apply_batches(const ApplyArgs<T> A, const Tables<T, n> tab) {
         mv<n, 1>(tab.S, r, v);
         lds_store<n>(Rc + bx, 1, v);
       }
+      if (act_next && !DBG(8)) load_coef(nxt);  // this chunk's coefficients are consumed
       __syncthreads();
       // P5: S^T along y
       if (act) {
@@ -288,19 +380,13 @@ apply_batches(const ApplyArgs<T> A, const Tables<T, n> tab) {
           lds_load<n>(Rc + bx, 1, v);
           if (mask && hn_flag3<n, 0>(mask, pa, pb, type)) hn_pencil<n, T, true>(Wl, type, v);
 #pragma unroll
-          for (int i = 0; i < n; ++i) lds_add(&acc[lm[bx + i]], v[i]);
+          for (int i = 0; i < n; ++i) lds_add(&acc[ix[i]], v[i]);
         }
       } else if (act) {
 #pragma unroll
-        for (int k = 0; k < n; ++k) lds_add(&acc[lm[bz + k * n2]], v[k]);
+        for (int k = 0; k < n; ++k) lds_add(&acc[iz[k]], v[k]);
       }
     } else {  // dim == 2
-      const int bx = n * pa;  // x-pencil (y=pa), stride 1
-      const int by = pa;      // y-pencil (x=pa), stride n
-      if (act) {
-#pragma unroll
-        for (int i = 0; i < n; ++i) u[i] = usrc[lm[bx + i]];
-      }
       if (HN && any_mask) {
         bool type;
         if (act) {
@@ -328,7 +414,7 @@ apply_batches(const ApplyArgs<T> A, const Tables<T, n> tab) {
         mvt<n, 1>(tab.S, u, w);
         mv<n, -1>(tab.Dt, w, g);
 #pragma unroll
-        for (int s = 0; s < n; ++s) g[s] *= cf[by + s * n];
+        for (int s = 0; s < n; ++s) g[s] *= L.cy[s];
         mvt<n, -1>(tab.Dt, g, r);
         lds_store<n>(Wc + by, n, w);
         lds_store<n>(Rc + by, n, r);
@@ -339,7 +425,7 @@ apply_batches(const ApplyArgs<T> A, const Tables<T, n> tab) {
         lds_load<n>(Wc + bx, 1, w);
         mv<n, -1>(tab.Dt, w, g);
 #pragma unroll
-        for (int s = 0; s < n; ++s) g[s] *= cf[bx + s];
+        for (int s = 0; s < n; ++s) g[s] *= L.cx[s];
         mvt<n, -1>(tab.Dt, g, r);
         lds_load<n>(Rc + bx, 1, v);
 #pragma unroll
@@ -347,6 +433,7 @@ apply_batches(const ApplyArgs<T> A, const Tables<T, n> tab) {
         mv<n, 1>(tab.S, r, v);
         lds_store<n>(Rc + bx, 1, v);
       }
+      if (act_next && !DBG(8)) load_coef(nxt);
       __syncthreads();
       // P3: S^T along y, scatter-add
       if (act) {
@@ -364,36 +451,99 @@ apply_batches(const ApplyArgs<T> A, const Tables<T, n> tab) {
           lds_load<n>(Rc + bx, 1, v);
           if (mask && hn_flag2<n, 0>(mask, pa, type)) hn_pencil<n, T, true>(Wl, type, v);
 #pragma unroll
-          for (int i = 0; i < n; ++i) lds_add(&acc[lm[bx + i]], v[i]);
+          for (int i = 0; i < n; ++i) lds_add(&acc[ix[i]], v[i]);
         }
       } else if (act) {
 #pragma unroll
-        for (int k = 0; k < n; ++k) lds_add(&acc[lm[by + k * n]], v[k]);
+        for (int k = 0; k < n; ++k) lds_add(&acc[iz[k]], v[k]);
       }
     }
-    // next chunk's first LDS write to Wc/Rc is separated from this chunk's last reads by the
-    // barriers above (Wc last read in P4/P2, Rc last read before the scatter; P0 writes Wc only)
+    // Wc is next written in P0 of the following chunk and was last read in P4 (P2 in 2D); Rc is next
+    // written in P2 (P1) and was last read before the scatter-add: both separated by barriers.
+    STAMP(4 + (base / CH < 8 ? base / CH : 8));
   }
   __syncthreads();
+  STAMP(13);
 
   // ---- 4. scatter (distribute_local_to_global fee_gpu.cuh:346-363 + identity rows
   //         constraint_handler_gpu.cu:276-289), one write per batch dof
-  for (int t = tid; t < nb; t += kBlock) {
-    const uint32_t gidx = A.bdofs[d0 + t];
-    const uint8_t f = A.bflags[d0 + t];
-    if (f & kFlagConstrained) {
-      if (!(f & kFlagAdd)) {
-        const T s = A.src[gidx];
-        A.dst[gidx] = A.add ? A.dst[gidx] + s : s;
+  if (TWOPASS) {
+    // batch dofs are ordered [interior | shared]: interior dofs belong to this batch alone and are
+    // final; partial sums of shared dofs go to the batch's contiguous halo slots (reduce_shared)
+    T *halo = A.halo + A.halo_off[b];
+    for (int t0 = 0; t0 < (DBG(4) ? 0 : nb); t0 += kGU * kBlock) {
+      uint32_t g[kGU];
+      T old[kGU];
+#pragma unroll
+      for (int j = 0; j < kGU; ++j) {
+        const int t = t0 + tid + j * kBlock;
+        g[j] = A.bdofs[d0 + (t < nb ? t : nb - 1)];
       }
-    } else {
-      const T val = acc[t];
-      if ((f & kFlagAdd) || A.add)
-        A.dst[gidx] += val;
-      else
-        A.dst[gidx] = val;
+      if (A.add) {  // uniform branch
+#pragma unroll
+        for (int j = 0; j < kGU; ++j) old[j] = A.dst[g[j] & 0x7fffffffu];
+      }
+#pragma unroll
+      for (int j = 0; j < kGU; ++j) {
+        const int t = t0 + tid + j * kBlock;
+        if (t < nint) {
+          if (!(g[j] >> 31)) A.dst[g[j]] = A.add ? old[j] + acc[t] : acc[t];
+        } else if (t < nb) {
+          halo[t - nint] = acc[t];  // constrained shared dofs: value ignored by reduce_shared
+        }
+      }
+    }
+  } else {
+    for (int t0 = 0; t0 < (DBG(4) ? 0 : nb); t0 += kGU * kBlock) {
+      uint32_t g[kGU];
+      uint8_t f[kGU];
+      T old[kGU];
+#pragma unroll
+      for (int j = 0; j < kGU; ++j) {
+        const int t = t0 + tid + j * kBlock;
+        const int tc = t < nb ? t : nb - 1;
+        g[j] = A.bdofs[d0 + tc];
+        f[j] = A.bflags[d0 + tc];
+      }
+      // later colours (and vmult_add) read-modify-write; the read is unconditional to keep the loads
+      // free of per-element branches
+#pragma unroll
+      for (int j = 0; j < kGU; ++j) old[j] = A.dst[g[j] & 0x7fffffffu];
+#pragma unroll
+      for (int j = 0; j < kGU; ++j) {
+        const int t = t0 + tid + j * kBlock;
+        if (t < nb && !(g[j] >> 31))
+          A.dst[g[j]] = ((f[j] & kFlagAdd) || A.add) ? old[j] + acc[t] : acc[t];
+      }
     }
   }
+#ifdef MFGPU_STAMPS
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#endif
+  STAMP(15);
+}
+
+// Second pass of the two-pass mode: one thread per shared dof sums the partial sums the touching
+// batches left in the halo buffer, in ascending batch order (deterministic, no atomics).
+// Constrained rows are identity (laplace_operator_gpu.h:300-302).
+template <typename T>
+__global__ void __launch_bounds__(256)
+reduce_shared(T *__restrict__ dst, const T *__restrict__ src, const T *__restrict__ halo,
+              const uint32_t *__restrict__ sdofs, const uint32_t *__restrict__ s_off,
+              const uint32_t *__restrict__ s_idx, uint32_t ns, int add) {
+  const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= ns) return;
+  const uint32_t o = sdofs[i];
+  const uint32_t g = o & 0x7fffffffu;
+  T val;
+  if (o >> 31) {
+    val = src[g];
+  } else {
+    const uint32_t j0 = s_off[i], j1 = s_off[i + 1];
+    val = halo[s_idx[j0]];
+    for (uint32_t j = j0 + 1; j < j1; ++j) val += halo[s_idx[j]];
+  }
+  dst[g] = add ? dst[g] + val : val;
 }
 
 // dofs no cell touches (e.g. hanging nodes eliminated from loc2glob): vmult gives
@@ -456,7 +606,7 @@ static size_t lds_bytes_t(uint32_t nb_max) {
 
 template <int dim, int n, typename T>
 static hipError_t launch_t(const ApplyArgs<T> &a, const double *S, const double *Dt, bool hn,
-                           uint32_t nbatches, hipStream_t st) {
+                           bool twopass, uint32_t nbatches, hipStream_t st) {
   Tables<T, n> tab;
   for (int i = 0; i < ((n + 1) / 2) * n; ++i) {
     tab.S[i] = (T)S[i];
@@ -464,20 +614,31 @@ static hipError_t launch_t(const ApplyArgs<T> &a, const double *S, const double 
   }
 
   const size_t lds = lds_bytes_t<dim, n, T>(a.nb_max);
-  if (hn)
-    hipLaunchKernelGGL((apply_batches<dim, n, T, true>), dim3(nbatches), dim3(kBlock), lds, st, a, tab);
+  if (hn && twopass)
+    hipLaunchKernelGGL((apply_batches<dim, n, T, true, true>), dim3(nbatches), dim3(kBlock), lds, st, a, tab);
+  else if (hn)
+    hipLaunchKernelGGL((apply_batches<dim, n, T, true, false>), dim3(nbatches), dim3(kBlock), lds, st, a, tab);
+  else if (twopass)
+    hipLaunchKernelGGL((apply_batches<dim, n, T, false, true>), dim3(nbatches), dim3(kBlock), lds, st, a, tab);
   else
-    hipLaunchKernelGGL((apply_batches<dim, n, T, false>), dim3(nbatches), dim3(kBlock), lds, st, a, tab);
+    hipLaunchKernelGGL((apply_batches<dim, n, T, false, false>), dim3(nbatches), dim3(kBlock), lds, st, a, tab);
   return hipGetLastError();
 }
 
 template <int dim, int n, typename T>
 static hipError_t configure_t(size_t lds) {
-  hipError_t e = hipFuncSetAttribute((const void *)apply_batches<dim, n, T, true>,
+  hipError_t e = hipFuncSetAttribute((const void *)apply_batches<dim, n, T, true, true>,
                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-  if (e != hipSuccess) return e;
-  return hipFuncSetAttribute((const void *)apply_batches<dim, n, T, false>,
-                             hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+  if (e == hipSuccess)
+    e = hipFuncSetAttribute((const void *)apply_batches<dim, n, T, true, false>,
+                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+  if (e == hipSuccess)
+    e = hipFuncSetAttribute((const void *)apply_batches<dim, n, T, false, true>,
+                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+  if (e == hipSuccess)
+    e = hipFuncSetAttribute((const void *)apply_batches<dim, n, T, false, false>,
+                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+  return e;
 }
 
 #define MFGPU_DISPATCH(CALL)                                \
@@ -527,10 +688,19 @@ hipError_t apply_configure(int dim, int n, size_t lds) {
 
 template <typename T>
 hipError_t apply_launch(int dim, int n, const ApplyArgs<T> &a, const double *S, const double *Dt,
-                        bool hn, uint32_t nbatches, hipStream_t st) {
-#define CALL(D, N) launch_t<D, N, T>(a, S, Dt, hn, nbatches, st)
+                        bool hn, bool twopass, uint32_t nbatches, hipStream_t st) {
+#define CALL(D, N) launch_t<D, N, T>(a, S, Dt, hn, twopass, nbatches, st)
   MFGPU_DISPATCH(CALL)
 #undef CALL
+}
+
+template <typename T>
+hipError_t reduce_launch(T *dst, const T *src, const T *halo, const uint32_t *sdofs, const uint32_t *s_off,
+                         const uint32_t *s_idx, uint32_t ns, int add, hipStream_t st) {
+  if (ns == 0) return hipSuccess;
+  hipLaunchKernelGGL(reduce_shared<T>, dim3((ns + 255) / 256), dim3(256), 0, st, dst, src, halo, sdofs,
+                     s_off, s_idx, ns, add);
+  return hipGetLastError();
 }
 
 template <typename T>
@@ -573,7 +743,9 @@ hipError_t fill_launch(T *v, size_t n, T a, hipStream_t st) {
   template size_t apply_lds_bytes<T>(int, int, uint32_t);                                               \
   template hipError_t apply_configure<T>(int, int, size_t);                                             \
   template hipError_t apply_launch<T>(int, int, const ApplyArgs<T> &, const double *, const double *,   \
-                                      bool, uint32_t, hipStream_t);                                     \
+                                      bool, bool, uint32_t, hipStream_t);                               \
+  template hipError_t reduce_launch<T>(T *, const T *, const T *, const uint32_t *, const uint32_t *,   \
+                                       const uint32_t *, uint32_t, int, hipStream_t);                   \
   template hipError_t orphan_launch<T>(T *, const T *, const uint32_t *, uint32_t, int, hipStream_t);   \
   template hipError_t coefficient_launch<T>(T *, const T *, size_t, int, hipStream_t);                  \
   template hipError_t fold_launch<T>(T *, const T *, const T *, const T *, const uint32_t *, uint32_t,  \

@@ -117,6 +117,10 @@ int build_plan(const mfgpu_desc &d, Plan &P) {
     constrained[d.constrained_dofs[i]] = 1;
   }
 
+  if (N >= 0x80000000u) {
+    set_error("n_dofs >= 2^31 is not supported (bit 31 of the dof lists carries the constrained flag)");
+    return MFGPU_EUNSUPPORTED;
+  }
   uint32_t Bmax, NBmax;
   default_batch_limits(d, Bmax, NBmax);
 
@@ -191,8 +195,10 @@ int build_plan(const mfgpu_desc &d, Plan &P) {
   }
   const uint32_t nb = (uint32_t)batches.size();
 
-  // ---- per batch: sorted unique dofs
+  // ---- per batch: unique dofs, ordered [interior ascending | shared ascending] where interior =
+  // touched by this batch only
   std::vector<std::vector<uint32_t>> bd(nb);
+  std::vector<uint32_t> ntouch(N, 0);
   for (uint32_t b = 0; b < nb; ++b) {
     std::vector<uint32_t> &v = bd[b];
     v.reserve(batches[b].size() * nd);
@@ -204,6 +210,15 @@ int build_plan(const mfgpu_desc &d, Plan &P) {
       set_error("internal: batch exceeds 65535 dofs");
       return MFGPU_EINVAL;
     }
+    for (uint32_t g : v) ntouch[g]++;
+  }
+  std::vector<uint32_t> nint(nb, 0);
+  for (uint32_t b = 0; b < nb; ++b) {
+    std::vector<uint32_t> &v = bd[b];
+    std::stable_partition(v.begin(), v.end(), [&](uint32_t g) { return ntouch[g] == 1; });
+    uint32_t k = 0;
+    while (k < v.size() && ntouch[v[k]] == 1) ++k;
+    nint[b] = k;
   }
 
   // ---- greedy colouring of batches (conflict = shared dof)
@@ -244,9 +259,13 @@ int build_plan(const mfgpu_desc &d, Plan &P) {
   std::vector<uint8_t> touched(N, 0);
   P.max_batch_dofs = P.max_batch_cells = 0;
   P.n_first = P.n_add = 0;
+  P.batch_nint.clear();
+  P.halo_off.assign(1, 0);
   for (uint32_t k = 0; k < nb; ++k) {
     const uint32_t b = order[k];
     const std::vector<uint32_t> &v = bd[b];
+    P.batch_nint.push_back(nint[b]);
+    P.halo_off.push_back(P.halo_off.back() + (uint32_t)(v.size() - nint[b]));
     for (uint32_t g : v) {
       uint8_t f = 0;
       if (constrained[g]) f |= kFlagConstrained;
@@ -257,7 +276,7 @@ int build_plan(const mfgpu_desc &d, Plan &P) {
         touched[g] = 1;
         ++P.n_first;
       }
-      P.bdofs.push_back(g);
+      P.bdofs.push_back(g | (constrained[g] ? 0x80000000u : 0u));  // bit 31: constrained row
       P.bflags.push_back(f);
     }
     for (uint32_t c : batches[b]) {
@@ -265,7 +284,9 @@ int build_plan(const mfgpu_desc &d, Plan &P) {
       P.cell_order.push_back(c);
       for (uint32_t i = 0; i < nd; ++i) {
         const uint32_t g = l2g[(uint64_t)c * nd + i];
-        P.lmap[pos * nd + i] = (uint16_t)(std::lower_bound(v.begin(), v.end(), g) - v.begin());
+        const auto first = ntouch[g] == 1 ? v.begin() : v.begin() + nint[b];
+        const auto last = ntouch[g] == 1 ? v.begin() + nint[b] : v.end();
+        P.lmap[pos * nd + i] = (uint16_t)(std::lower_bound(first, last, g) - v.begin());
       }
     }
     P.batch_cell_off.push_back((uint32_t)P.cell_order.size());
@@ -276,9 +297,28 @@ int build_plan(const mfgpu_desc &d, Plan &P) {
   P.orphans.clear();
   for (uint32_t g = 0; g < N; ++g)
     if (!touched[g]) P.orphans.push_back(g | (constrained[g] ? 0x80000000u : 0u));
-  if (N >= 0x80000000u && !P.orphans.empty()) {
-    set_error("n_dofs >= 2^31 with orphan dofs is not supported");
-    return MFGPU_EUNSUPPORTED;
+  // shared-dof CSR for the second pass: halo slots in ascending execution order of the batches
+  {
+    std::vector<uint32_t> sid(N, NONE);
+    P.sdofs.clear();
+    for (uint32_t g = 0; g < N; ++g)
+      if (ntouch[g] >= 2) {
+        sid[g] = (uint32_t)P.sdofs.size();
+        P.sdofs.push_back(g | (constrained[g] ? 0x80000000u : 0u));
+      }
+    const size_t ns = P.sdofs.size();
+    P.s_off.assign(ns + 1, 0);
+    for (size_t i = 0; i < ns; ++i) P.s_off[i + 1] = P.s_off[i] + ntouch[P.sdofs[i] & 0x7fffffffu];
+    P.s_idx.assign(P.s_off[ns], 0);
+    std::vector<uint32_t> fill(P.s_off.begin(), P.s_off.end() - 1);
+    for (uint32_t k = 0; k < nb; ++k) {
+      const uint32_t ni = P.batch_nint[k];
+      const uint32_t d0 = P.batch_dof_off[k], d1 = P.batch_dof_off[k + 1];
+      for (uint32_t t = d0 + ni; t < d1; ++t) {
+        const uint32_t g = P.bdofs[t] & 0x7fffffffu;
+        P.s_idx[fill[sid[g]]++] = P.halo_off[k] + (t - d0 - ni);
+      }
+    }
   }
   return 0;
 }
@@ -316,6 +356,11 @@ int64_t mfgpu_plan_array_u32(const mfgpu_plan *p, int what, const uint32_t **ptr
     case 3: v = &p->plan.cell_order; break;
     case 4: v = &p->plan.bdofs; break;
     case 5: v = &p->plan.orphans; break;
+    case 6: v = &p->plan.batch_nint; break;
+    case 7: v = &p->plan.halo_off; break;
+    case 8: v = &p->plan.sdofs; break;
+    case 9: v = &p->plan.s_off; break;
+    case 10: v = &p->plan.s_idx; break;
     default: mfgpu::set_error("bad array id"); return MFGPU_EINVAL;
   }
   *ptr = v->data();

@@ -12,10 +12,11 @@ import os
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(os.path.dirname(_HERE), "lib", "libmfgpu.so")
+# MFGPU_LIB selects another build of the SAME sources (tools/stamps.py: lib/libmfgpu_diag.so)
+LIB_PATH = os.environ.get("MFGPU_LIB") or os.path.join(os.path.dirname(_HERE), "lib", "libmfgpu.so")
 
 F64, F32 = 0, 1
-UNIFORM_J0, HANGING_NODES = 1, 2
+UNIFORM_J0, HANGING_NODES, COLORED_SCATTER = 1, 2, 1 << 8
 
 
 class MfgpuError(RuntimeError):
@@ -184,7 +185,8 @@ class Mesh:
 
 def make_desc(dim, degree, n_dofs, loc2glob, JxW, inv_jac, coefficient, constrained,
               shape_values, shape_gradients, number_type=F64, constraint_mask=None,
-              constraint_weights=None, quadrature_points=None, max_cells_per_batch=0, max_dofs_per_batch=0):
+              constraint_weights=None, quadrature_points=None, max_cells_per_batch=0, max_dofs_per_batch=0,
+              colored=False):
     """Build a Desc from numpy arrays; returns (desc, keepalive list)."""
     dt = np_dtype(number_type)
     keep = []
@@ -198,7 +200,7 @@ def make_desc(dim, degree, n_dofs, loc2glob, JxW, inv_jac, coefficient, constrai
 
     d = Desc()
     d.dim, d.degree, d.number_type = dim, degree, number_type
-    d.flags = UNIFORM_J0 | (HANGING_NODES if constraint_mask is not None else 0)
+    d.flags = UNIFORM_J0 | (HANGING_NODES if constraint_mask is not None else 0) | (COLORED_SCATTER if colored else 0)
     l2g = np.ascontiguousarray(loc2glob, dtype=np.uint32)
     d.n_dofs = int(n_dofs)
     d.n_cells = l2g.size // ((degree + 1) ** dim)
@@ -245,8 +247,14 @@ class Plan:
     batch_dof_off = property(lambda s: s._u32(1))
     color_batch_off = property(lambda s: s._u32(2))
     cell_order = property(lambda s: s._u32(3))
-    bdofs = property(lambda s: s._u32(4))
+    bdofs = property(lambda s: s._u32(4) & np.uint32(0x7fffffff))       # global ids
+    bdofs_constrained = property(lambda s: (s._u32(4) >> np.uint32(31)).astype(bool))
     orphans = property(lambda s: s._u32(5))
+    batch_nint = property(lambda s: s._u32(6))
+    halo_off = property(lambda s: s._u32(7))
+    sdofs = property(lambda s: s._u32(8))
+    s_off = property(lambda s: s._u32(9))
+    s_idx = property(lambda s: s._u32(10))
 
     @property
     def lmap(self):
@@ -328,8 +336,8 @@ class Operator:
     def plan_stats(self):
         s = (C.c_uint64 * 8)()
         _check(lib().mfgpu_plan_stats(self._h, s))
-        keys = ["n_batches", "n_colors", "batch_dofs", "max_batch_dofs", "max_batch_cells", "n_orphans",
-                "first_touch", "rmw_adds"]
+        keys = ["n_batches", "n_launches", "batch_dofs", "max_batch_dofs", "max_batch_cells", "n_orphans",
+                "first_touch_or_shared_dofs", "rmw_adds_or_halo_slots"]
         return dict(zip(keys, [int(v) for v in s]))
 
     def profile_enable(self, on=True):

@@ -44,6 +44,12 @@ extern "C" {
 #define MFGPU_HANGING_NODES (1u << 1) /* constraint_mask is given (MATRIX_FREE_HANGING_NODES,
                                          fee_gpu.cuh:333-335,349-351)                           */
 
+#define MFGPU_COLORED_SCATTER (1u << 8) /* scatter mode: one launch per batch colour with first-touch
+                                         stores and later-colour adds (the reference's use_coloring idea,
+                                         matrix_free_gpu.h:374-379, fee_gpu.cuh:359-362, at batch level).
+                                         Default is the two-pass mode: one sweep over all batches, batch-
+                                         surface partial sums reduced per dof by a second kernel.           */
+
 typedef struct mfgpu_handle mfgpu_handle; /* replaces MatrixFreeGpu + coefficient + ConstraintHandlerGpu
                                              inside LaplaceOperatorGpu (laplace_operator_gpu.h:85-95) */
 
@@ -107,8 +113,9 @@ void mfgpu_destroy(mfgpu_handle *h);
 const char *mfgpu_last_error(void);
 
 /* Plan statistics (for DESIGN/bench reporting and the CPU-side host-logic tests).
- * stats[0]=n_batches [1]=n_colors [2]=total batch dofs [3]=max dofs/batch [4]=max cells/batch
- * [5]=n_orphan_dofs [6]=first-touch stores [7]=read-modify-write adds                         */
+ * stats[0]=n_batches [1]=cell-loop launches per vmult (colours; 1 in two-pass mode) [2]=total batch dofs
+ * [3]=max dofs/batch [4]=max cells/batch [5]=n_orphan_dofs
+ * [6]=first-touch stores (coloured) / shared dofs (two-pass) [7]=RMW adds (coloured) / halo slots (two-pass) */
 int mfgpu_plan_stats(const mfgpu_handle *h, uint64_t stats[8]);
 
 /* Average device time of the cell-loop kernels of the most recent mfgpu_vmult* calls, measured
@@ -123,6 +130,7 @@ int mfgpu_plan_create(const mfgpu_desc *desc, mfgpu_plan **out);
 void mfgpu_plan_destroy(mfgpu_plan *p);
 /* what: 0 batch_cell_off[n_batches+1] 1 batch_dof_off[n_batches+1] 2 color_batch_off[n_colors+1]
  *       3 cell_order[n_cells] (plan position -> caller cell) 4 bdofs[total] 5 orphans[n_orphans]
+ *       6 batch_nint[n_batches] 7 halo_off[n_batches+1] 8 sdofs[n_shared] 9 s_off[n_shared+1] 10 s_idx
  * returns element count, *ptr = host pointer valid until mfgpu_plan_destroy                  */
 int64_t mfgpu_plan_array_u32(const mfgpu_plan *p, int what, const uint32_t **ptr);
 int64_t mfgpu_plan_lmap(const mfgpu_plan *p, const uint16_t **ptr);   /* [n_cells*n^dim], plan order */

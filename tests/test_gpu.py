@@ -43,9 +43,12 @@ CASES = [(2, 1, 7), (2, 2, 32), (2, 3, 5), (2, 4, 4), (2, 5, 3), (2, 6, 3),
 
 @pytest.mark.parametrize("dim,p,n", CASES)
 @pytest.mark.parametrize("nt", [mf.F64, mf.F32])
-def test_vmult_matches_oracle(dim, p, n, nt):
+@pytest.mark.parametrize("colored", [False, True])
+def test_vmult_matches_oracle(dim, p, n, nt, colored):
     mesh = mf.Mesh.uniform(dim, p, n, number_type=nt)
     od = oracle_desc_from_mesh(mesh, dtype=np.float64)
+    if colored:
+        mesh.desc.flags |= mf.COLORED_SCATTER
     op = mf.Operator(mesh.desc, mesh)
     assert op.n() == mesh.n_dofs
     x = np.random.default_rng(dim * 100 + p * 10 + n).standard_normal(mesh.n_dofs)
@@ -53,10 +56,13 @@ def test_vmult_matches_oracle(dim, p, n, nt):
     assert rel(y, o.vmult(od, x.astype(mf.np_dtype(nt)).astype(np.float64))) <= TOL[nt]
 
 
+@pytest.mark.parametrize("colored", [False, True])
 @pytest.mark.parametrize("dim,p,n", [(2, 2, 9), (3, 4, 3), (3, 2, 5)])
-def test_vmult_add_matches_oracle(dim, p, n):
+def test_vmult_add_matches_oracle(dim, p, n, colored):
     mesh = mf.Mesh.uniform(dim, p, n)
     od = oracle_desc_from_mesh(mesh)
+    if colored:
+        mesh.desc.flags |= mf.COLORED_SCATTER
     op = mf.Operator(mesh.desc, mesh)
     rng = np.random.default_rng(11)
     x, y0 = rng.standard_normal(mesh.n_dofs), rng.standard_normal(mesh.n_dofs)
@@ -81,7 +87,8 @@ def test_independent_oracle_mesh_and_given_coefficient():
     od = o.uniform_mesh_desc(3, 4, 4, coefficient=lambda x: 1.0 + x[..., 0] ** 2 + 0.5 * np.sin(x[..., 1]))
     x = np.random.default_rng(3).standard_normal(od.n_dofs)
     ref = o.vmult(od, x)
-    for kw in ({}, dict(max_cells_per_batch=1), dict(max_cells_per_batch=8), dict(max_cells_per_batch=64, max_dofs_per_batch=4000)):
+    for kw in ({}, dict(max_cells_per_batch=1), dict(max_cells_per_batch=8), dict(max_cells_per_batch=64, max_dofs_per_batch=4000),
+               dict(colored=True), dict(colored=True, max_cells_per_batch=8)):
         desc, keep = desc_from_oracle(od, **kw)
         op = mf.Operator(desc, keep)
         assert rel(gpu_vmult(op, x), ref) <= 1e-12, kw
@@ -119,13 +126,14 @@ def test_ragged_mesh_with_orphans():
     keep_cells = np.array([0, 1, 2, 5, 10, 15])
     od2 = o.Desc(2, 2, od.n_dofs, od.loc2glob[keep_cells], od.JxW[keep_cells], od.inv_jac[keep_cells],
                  od.coefficient[keep_cells], od.constrained)
-    desc, keep = desc_from_oracle(od2, max_cells_per_batch=3)
-    op = mf.Operator(desc, keep)
-    assert op.plan_stats()["n_orphans"] > 0
-    x = np.random.default_rng(1).standard_normal(od.n_dofs)
-    assert rel(gpu_vmult(op, x), o.vmult(od2, x)) <= 1e-12
-    y0 = np.random.default_rng(2).standard_normal(od.n_dofs)
-    assert rel(gpu_vmult(op, x, y0=y0), o.vmult_add(od2, y0, x)) <= 1e-12
+    for colored in (False, True):
+        desc, keep = desc_from_oracle(od2, max_cells_per_batch=3, colored=colored)
+        op = mf.Operator(desc, keep)
+        assert op.plan_stats()["n_orphans"] > 0
+        x = np.random.default_rng(1).standard_normal(od.n_dofs)
+        assert rel(gpu_vmult(op, x), o.vmult(od2, x)) <= 1e-12
+        y0 = np.random.default_rng(2).standard_normal(od.n_dofs)
+        assert rel(gpu_vmult(op, x, y0=y0), o.vmult_add(od2, y0, x)) <= 1e-12
 
 
 def test_errors_are_loud():
@@ -149,7 +157,7 @@ def test_full_size_properties(n):
     assert N == 217 ** 3
     op = mf.Operator(mesh.desc, mesh)
     st = op.plan_stats()
-    assert st["n_colors"] <= 16
+    assert st["n_launches"] == 1
     con = mesh.arrays()["constrained_dofs"]
     rng = np.random.default_rng(0)
     u, v = rng.standard_normal(N), rng.standard_normal(N)

@@ -78,15 +78,29 @@ def _plan_invariants(od, plan):
     con = np.zeros(od.n_dofs, bool)
     con[od.constrained] = True
     touched = np.zeros(od.n_dofs, bool)
+    ntouch = np.zeros(od.n_dofs, int)
+    for b in range(nb):
+        ntouch[bdofs[bdo[b]:bdo[b + 1]]] += 1
+    # shared-dof CSR of the two-pass mode
+    sd, so, si = plan.sdofs, plan.s_off, plan.s_idx
+    np.testing.assert_array_equal(sd & 0x7fffffff, np.nonzero(ntouch >= 2)[0])
+    np.testing.assert_array_equal(np.diff(so), ntouch[sd & 0x7fffffff])
+    assert sorted(si.tolist()) == list(range(int(plan.halo_off[-1])))   # every halo slot read exactly once
     for c in range(len(cbo) - 1):
         seen = np.zeros(od.n_dofs, bool)
         for b in range(cbo[c], cbo[c + 1]):
             g = bdofs[bdo[b]:bdo[b + 1]]
             f = bflags[bdo[b]:bdo[b + 1]]
-            assert (np.diff(g.astype(np.int64)) > 0).all()          # ascending, unique
+            ni = int(plan.batch_nint[b])
+            assert (np.diff(g[:ni].astype(np.int64)) > 0).all()     # [interior asc | shared asc], unique
+            assert (np.diff(g[ni:].astype(np.int64)) > 0).all()
+            assert len(np.unique(g)) == len(g)
+            assert (ntouch[g[:ni]] == 1).all() and (ntouch[g[ni:]] >= 2).all()
+            assert plan.halo_off[b + 1] - plan.halo_off[b] == len(g) - ni
             assert not seen[g].any()                                 # colour is conflict-free
             seen[g] = True
             np.testing.assert_array_equal((f & 1).astype(bool), con[g])
+            np.testing.assert_array_equal(plan.bdofs_constrained[bdo[b]:bdo[b + 1]], con[g])
             np.testing.assert_array_equal((f & 2).astype(bool), touched[g])  # first toucher stores
             cells = np.arange(bco[b], bco[b + 1])
             np.testing.assert_array_equal(g[lmap[cells]], od.loc2glob[order[cells]])
@@ -109,9 +123,11 @@ def test_plan_invariants_and_dataflow(dim, p, n, kw):
     rng = np.random.default_rng(0)
     x, y0 = rng.standard_normal(od.n_dofs), rng.standard_normal(od.n_dofs)
     ref = o.vmult(od, x)
-    np.testing.assert_allclose(emulate_plan_vmult(od, plan, x), ref, rtol=0, atol=1e-12 * np.abs(ref).max())
+    for tp in (False, True):
+        np.testing.assert_allclose(emulate_plan_vmult(od, plan, x, twopass=tp), ref, rtol=0, atol=1e-12 * np.abs(ref).max())
     ref = o.vmult_add(od, y0, x)
-    np.testing.assert_allclose(emulate_plan_vmult(od, plan, x, y0), ref, rtol=0, atol=1e-12 * np.abs(ref).max())
+    for tp in (False, True):
+        np.testing.assert_allclose(emulate_plan_vmult(od, plan, x, y0, twopass=tp), ref, rtol=0, atol=1e-12 * np.abs(ref).max())
 
 
 def test_plan_orphans_and_ragged_mesh():
@@ -126,7 +142,8 @@ def test_plan_orphans_and_ragged_mesh():
     assert len(plan.orphans) > 0
     x = np.random.default_rng(1).standard_normal(od.n_dofs)
     ref = o.vmult(od2, x)
-    np.testing.assert_allclose(emulate_plan_vmult(od2, plan, x), ref, atol=1e-12 * np.abs(ref).max())
+    for tp in (False, True):
+        np.testing.assert_allclose(emulate_plan_vmult(od2, plan, x, twopass=tp), ref, atol=1e-12 * np.abs(ref).max())
 
 
 def test_batching_quality_structured():
@@ -137,6 +154,7 @@ def test_batching_quality_structured():
     nb = len(plan.batch_cell_off) - 1
     assert nb == 27, nb
     assert np.diff(plan.batch_dof_off).max() == 13 ** 3
+    assert plan.batch_nint.min() == 11 ** 3  # the one batch in the middle of the 3x3x3 arrangement
     assert len(plan.color_batch_off) - 1 == 8
 
 

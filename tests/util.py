@@ -23,7 +23,7 @@ def desc_from_oracle(od: o.Desc, number_type=mf.F64, **kw):
                         od.constraint_mask, od.weights if od.constraint_mask is not None else None, **kw)
 
 
-def emulate_plan_vmult(od: o.Desc, plan: "mf.Plan", src, dst_in=None):
+def emulate_plan_vmult(od: o.Desc, plan: "mf.Plan", src, dst_in=None, twopass=False):
     """numpy emulation of the kernel's DATA FLOW driven by the plan arrays (gather through
     bdofs/lmap, per-batch accumulation, first-touch store / add, orphans), with the oracle as the
     cell kernel.  Checks the planner, not the HIP code."""
@@ -31,6 +31,8 @@ def emulate_plan_vmult(od: o.Desc, plan: "mf.Plan", src, dst_in=None):
     dst = np.full(od.n_dofs, np.nan) if not add else np.array(dst_in, dtype=np.float64)
     bco, bdo, order = plan.batch_cell_off, plan.batch_dof_off, plan.cell_order
     bdofs, bflags, lmap = plan.bdofs, plan.bflags, plan.lmap
+    nint, hoff = plan.batch_nint, plan.halo_off
+    halo = np.full(int(hoff[-1]), np.nan)
     # permuted oracle desc (plan cell order)
     pd = o.Desc(od.dim, od.degree, od.n_dofs, od.loc2glob[order], od.JxW[order], od.inv_jac[order],
                 od.coefficient[order], od.constrained,
@@ -49,12 +51,25 @@ def emulate_plan_vmult(od: o.Desc, plan: "mf.Plan", src, dst_in=None):
         loc = o.cell_apply(sub, usrc[lmap[cells]])
         np.add.at(acc, lmap[cells].reshape(-1), loc.reshape(-1))
         con, addf = (f & 1).astype(bool), (f & 2).astype(bool)
+        if twopass:
+            ni = int(nint[b])
+            gi, ci = g[:ni], con[:ni]
+            val = np.where(ci, src[gi], acc[:ni])
+            dst[gi] = (dst[gi] if add else 0.0) + val
+            halo[hoff[b]:hoff[b + 1]] = acc[ni:]
+            continue
         first_con = con & ~addf
         dst[g[first_con]] = (dst[g[first_con]] if add else 0.0) + src[g[first_con]]
         free_add = ~con & (addf | add)
         dst[g[free_add]] += acc[free_add]
         free_store = ~con & ~(addf | add)
         dst[g[free_store]] = acc[free_store]
+    if twopass:
+        sd, so, si = plan.sdofs, plan.s_off, plan.s_idx
+        for i in range(len(sd)):
+            g = int(sd[i] & 0x7fffffff)
+            val = src[g] if (sd[i] >> 31) else sum(halo[si[so[i]:so[i + 1]]])
+            dst[g] = (dst[g] if add else 0.0) + val
     for oo in plan.orphans:
         g = int(oo & 0x7fffffff)
         s = src[g] if (oo >> 31) else 0.0
