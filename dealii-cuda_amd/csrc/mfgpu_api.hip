@@ -39,6 +39,8 @@ struct mfgpu_handle {
   void *d_halo = nullptr;
   unsigned long long *d_stamps = nullptr;  // diagnostic build only
   size_t lds = 0, device_bytes = 0;
+  uint32_t max_grid = 0;  // resident workgroups of the cell-loop kernel
+  int kb = 256;           // threads per workgroup of the cell-loop kernel
   // profiling
   bool prof = false;
   std::vector<hipEvent_t> ev;  // start/stop pairs
@@ -160,12 +162,24 @@ int create_typed(mfgpu_handle *h, const mfgpu_desc &d) {
     set_error(std::string("coefficient fold: ") + hipGetErrorString(e));
     return MFGPU_EHIP;
   }
-  h->lds = apply_lds_bytes<T>(P.dim, P.n, P.max_batch_dofs);
+  h->kb = 256;
+  if (const char *e = getenv("MFGPU_THREADS")) h->kb = atoi(e) == 512 ? 512 : 256;
+  h->lds = apply_lds_bytes<T>(P.dim, P.n, P.max_batch_dofs, h->kb);
   if (h->lds > 160 * 1024) {
     set_error("batch needs more than 160 KiB of LDS; lower max_dofs_per_batch");
     return MFGPU_EINVAL;
   }
-  HIP_TRY(apply_configure<T>(P.dim, P.n, h->lds));
+  HIP_TRY(apply_configure<T>(P.dim, P.n, h->lds, h->kb));
+  // persistent grid: as many workgroups as fit on the chip (each loops over its batches)
+  int per_cu = 0, dev = 0;
+  hipDeviceProp_t prop;
+  HIP_TRY(apply_occupancy<T>(P.dim, P.n, h->hn, h->twopass, h->kb, h->lds, &per_cu));
+  HIP_TRY(hipGetDevice(&dev));
+  HIP_TRY(hipGetDeviceProperties(&prop, dev));
+  if (per_cu < 1) per_cu = 1;
+  h->max_grid = (uint32_t)per_cu * (uint32_t)prop.multiProcessorCount;
+  if (const char *e = getenv("MFGPU_GRID"))
+    if (atoi(e) > 0) h->max_grid = (uint32_t)atoi(e);  // tuning experiments only
   return 0;
 }
 
@@ -210,7 +224,9 @@ int vmult_typed(mfgpu_handle *h, void *dst, const void *src, hipStream_t st, int
       }
       HIP_TRY(hipEventRecord(h->ev[h->ev_used], st));
     }
-    HIP_TRY(apply_launch<T>(P.dim, P.n, a, h->S.data(), h->Dt.data(), h->hn, h->twopass, nbat, st));
+    a.batch_end = a.batch0 + nbat;
+    HIP_TRY(apply_launch<T>(P.dim, P.n, a, h->S.data(), h->Dt.data(), h->hn, h->twopass, h->kb,
+                            nbat < h->max_grid ? nbat : h->max_grid, st));
     if (h->prof) {
       HIP_TRY(hipEventRecord(h->ev[h->ev_used + 1], st));
       h->ev_used += 2;

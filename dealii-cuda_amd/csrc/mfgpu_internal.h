@@ -18,7 +18,6 @@ inline int ipow(int a, int e) {
   return r;
 }
 
-constexpr int kBlock = 256;           // threads per workgroup of the cell-loop kernel (4 waves)
 constexpr uint8_t kFlagConstrained = 1;  // batch dof is a constrained row (identity)
 constexpr uint8_t kFlagAdd = 2;          // batch is NOT the first toucher: dst += (else dst =)
 

@@ -130,7 +130,7 @@ __device__ __forceinline__ void lds_add(T *p, T v) {
     if (A.stamps && threadIdx.x == 0) {                                                   \
       unsigned long long t_;                                                              \
       asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_)::"memory");           \
-      A.stamps[(size_t)(A.batch0 + blockIdx.x) * 16 + (k)] = t_;                          \
+      A.stamps[(size_t)b * 16 + (k)] = t_;                          \
     }                                                                                     \
   } while (0)
 #define DBG(bit) (A.dbg & (bit))
@@ -139,20 +139,12 @@ __device__ __forceinline__ void lds_add(T *p, T v) {
 #define DBG(bit) 0
 #endif
 
-constexpr int kGU = 9;  // gather/scatter unroll: kGU*kBlock batch dofs per pass, all loads in flight
+constexpr int kMaxBatchDofs = 2304;  // a batch's dof list and source values live in registers
 
-// Per-chunk global streams of one thread: folded coefficient in the three pencil layouts and the
-// local->batch index map in the first (x) and last (z / y in 2D) layout.  They are issued one phase
-// before use so that their latency hides behind the contraction stages.
-template <int n, typename T>
-struct ChunkLoads {
-  T cz[n], cy[n], cx[n];
-  uint16_t ix[n], iz[n];
-};
-
-template <int dim, int n, typename T, bool HN, bool TWOPASS>
+template <int dim, int n, typename T, bool HN, bool TWOPASS, int kBlock>
 __global__ void __launch_bounds__(kBlock)
 apply_batches(const ApplyArgs<T> A, const Tables<T, n> tab) {
+  constexpr int kGU = (kMaxBatchDofs + kBlock - 1) / kBlock;  // all gather loads of a batch in flight
   constexpr int nd = (dim == 3) ? n * n * n : n * n;
   constexpr int P = nd / n;          // pencils per cell
   constexpr int CH = kBlock / P;     // cells per chunk
@@ -163,14 +155,43 @@ apply_batches(const ApplyArgs<T> A, const Tables<T, n> tab) {
   T *acc = usrc + A.nb_max;
   T *Wb = acc + A.nb_max;
   T *Rb = Wb + CHND;
-  T *Wl = Rb + CHND;     // hanging-node weights (HN only), broadcast reads
+  T *Cb = Rb + CHND;     // folded coefficient of the current chunk
+  T *Wl = Cb + CHND;     // hanging-node weights (HN only), broadcast reads
+  uint16_t *Lb = reinterpret_cast<uint16_t *>(Wl + n2);  // local->batch dof map of the current chunk
 
   const int tid = threadIdx.x;
-  const uint32_t b = A.batch0 + blockIdx.x;
-  const uint32_t c0 = A.batch_cell_off[b], c1 = A.batch_cell_off[b + 1];
-  const uint32_t d0 = A.batch_dof_off[b];
-  const int nb = (int)(A.batch_dof_off[b + 1] - d0);
-  const int ncell = (int)(c1 - c0);
+  // Workgroup loops over batches b, b + gridDim.x, ... of [batch0, batch_end) (grid = resident
+  // workgroups).  Cross-batch register prefetch of the dof list / source values was tried and dropped:
+  // hipcc waits vmcnt(0) at the loop back-edge, so it bought nothing and cost 60 VGPRs (occupancy).
+  const uint32_t bend = A.batch_end;
+  uint32_t b = A.batch0 + blockIdx.x;
+  if (b >= bend) return;
+  uint32_t c0, d0, hoff;
+  int nb, ncell, nint;
+  auto load_meta = [&](uint32_t bb, uint32_t &c0_, int &ncell_, uint32_t &d0_, int &nb_, int &nint_,
+                       uint32_t &hoff_) {
+    c0_ = A.batch_cell_off[bb];
+    ncell_ = (int)(A.batch_cell_off[bb + 1] - c0_);
+    d0_ = A.batch_dof_off[bb];
+    nb_ = (int)(A.batch_dof_off[bb + 1] - d0_);
+    nint_ = TWOPASS ? (int)A.batch_nint[bb] : 0;
+    hoff_ = TWOPASS ? A.halo_off[bb] : 0u;
+  };
+  // All loads are unconditional on clamped indices: predicated loads become one branch +
+  // s_waitcnt vmcnt(0) EACH (18 serialized memory round trips in an earlier version).
+  auto load_dofs = [&](uint32_t d0_, int nb_, uint32_t (&g_)[kGU], uint8_t (&f_)[kGU]) {
+#pragma unroll
+    for (int j = 0; j < kGU; ++j) {
+      const int t = tid + j * kBlock;
+      const int tc = t < nb_ ? t : nb_ - 1;
+      g_[j] = A.bdofs[d0_ + tc];
+      f_[j] = TWOPASS ? (uint8_t)0 : A.bflags[d0_ + tc];
+    }
+  };
+  auto load_src = [&](const uint32_t (&g_)[kGU], T (&sv_)[kGU]) {
+#pragma unroll
+    for (int j = 0; j < kGU; ++j) sv_[j] = DBG(2) ? T(0) : A.src[g_[j] & 0x7fffffffu];
+  };
 
   const int lc = tid / P;
   const int pen = tid - lc * P;
@@ -182,78 +203,85 @@ apply_batches(const ApplyArgs<T> A, const Tables<T, n> tab) {
   constexpr int sl = (dim == 3) ? n2 : n;                 // stride of the last direction
   const int bl = (dim == 3) ? bz : by;                    // pencil base of the last direction
 
-  ChunkLoads<n, T> L;
-  auto load_idx = [&](int base) {
-    const uint16_t *lm = A.lmap + ((size_t)c0 + base + lc) * nd;
+  // Per-chunk streams (folded coefficient, local->batch index map) are contiguous in plan order.  They
+  // are fetched ONE CHUNK AHEAD with fully coalesced loads into registers and staged in LDS, from where
+  // every pencil layout reads them.  Loading them per layout straight from global memory touched up to
+  // 64 distinct cache lines per wave instruction (x-layout: 40-byte lane stride) and made the CU's L1
+  // line-access rate the bottleneck (profiles/, round 1).
+  constexpr int PF = (CHND + kBlock - 1) / kBlock;
+  T pc[PF];
+  uint16_t pl[PF];
+  auto prefetch = [&](uint32_t cell0, int cnt) {
+    const T *cg = A.coef + (size_t)cell0 * nd;
+    const uint16_t *lg = A.lmap + (size_t)cell0 * nd;
 #pragma unroll
-    for (int i = 0; i < n; ++i) {
-      L.ix[i] = lm[bx + i];
-      L.iz[i] = lm[bl + i * sl];
+    for (int j = 0; j < PF; ++j) {
+      const int i = tid + j * kBlock;
+      const int ic = i < cnt ? i : cnt - 1;  // clamped, branch-free
+      pc[j] = cg[ic];
+      pl[j] = lg[ic];
     }
   };
-  auto load_coef = [&](int base) {
-    const T *cf = A.coef + ((size_t)c0 + base + lc) * nd;
+  auto stage = [&](int cnt) {
 #pragma unroll
-    for (int i = 0; i < n; ++i) {
-      if (dim == 3) L.cz[i] = cf[bz + i * n2];
-      L.cy[i] = cf[by + i * n];
-      L.cx[i] = cf[bx + i];
+    for (int j = 0; j < PF; ++j) {
+      const int i = tid + j * kBlock;
+      if (i < cnt) {
+        Cb[i] = pc[j];
+        Lb[i] = pl[j];
+      }
     }
   };
-  STAMP(0);
-  const bool act0 = (tid < CH * P) && (lc < ncell);
-  if (act0 && !DBG(8)) {
-    load_idx(0);
-    load_coef(0);  // in flight during the gather
-  }
   if (HN) {
     for (int t = tid; t < n2; t += kBlock) Wl[t] = A.hn_weights[t];
   }
-  // ---- 1. gather (read_dof_values, fee_gpu.cuh:323-331, once per batch dof).  All loads are
-  // unconditional on clamped indices: predicated loads become one branch + s_waitcnt vmcnt(0) EACH
-  // (18 serialized memory round trips in an earlier version of this loop).
-  // bdofs bit 31 = constrained row: reads as 0 (constraint_handler_gpu.cu:258-259) and, if this batch
-  // owns the row, dst = src is written here (identity rows, constraint_handler_gpu.cu:286).
-  const int nint = TWOPASS ? (int)A.batch_nint[b] : 0;
-  for (int t0 = 0; t0 < nb; t0 += kGU * kBlock) {
-    uint32_t g[kGU];
-    uint8_t f[kGU];
-    T sv[kGU];
+  T *Wc = Wb + lc * nd;
+  T *Rc = Rb + lc * nd;
+  while (true) {
+  STAMP(0);
+  load_meta(b, c0, ncell, d0, nb, nint, hoff);
+  const int cnt0 = (ncell < CH ? ncell : CH) * nd;
+  if (!DBG(8)) prefetch(c0, cnt0);  // in flight during the gather
+  // ---- 1. gather (read_dof_values, fee_gpu.cuh:323-331, once per batch dof).  bdofs bit 31 = constrained row: reads as 0 (constraint_handler_gpu.cu:258-259) and,
+  // if this batch owns the row, dst = src is written here (identity rows, :286).
+  {
+    uint32_t G[kGU];
+    uint8_t F[kGU];
+    T SV[kGU];
+    load_dofs(d0, nb, G, F);
+    load_src(G, SV);
 #pragma unroll
     for (int j = 0; j < kGU; ++j) {
-      const int t = t0 + tid + j * kBlock;
-      const int tc = t < nb ? t : nb - 1;
-      g[j] = A.bdofs[d0 + tc];
-      if (!TWOPASS) f[j] = A.bflags[d0 + tc];
-    }
-#pragma unroll
-    for (int j = 0; j < kGU; ++j) sv[j] = DBG(2) ? T(0) : A.src[g[j] & 0x7fffffffu];
-#pragma unroll
-    for (int j = 0; j < kGU; ++j) {
-      const int t = t0 + tid + j * kBlock;
-      const bool con = (g[j] >> 31) != 0;
+      const int t = tid + j * kBlock;
+      const bool con = (G[j] >> 31) != 0;
       if (t < nb) {
-        usrc[t] = con ? T(0) : sv[j];
+        usrc[t] = con ? T(0) : SV[j];
         acc[t] = T(0);
-        const bool owner = TWOPASS ? (t < nint) : !(f[j] & kFlagAdd);
+        const bool owner = TWOPASS ? (t < nint) : !(F[j] & kFlagAdd);
         if (con && owner) {
-          T *d = A.dst + (g[j] & 0x7fffffffu);
-          *d = A.add ? *d + sv[j] : sv[j];
+          T *d = A.dst + (G[j] & 0x7fffffffu);
+          *d = A.add ? *d + SV[j] : SV[j];
         }
       }
     }
   }
+  const uint32_t bn = b + gridDim.x;
+  const bool has_nb = bn < bend;
   STAMP(2);
+  stage(cnt0);
   __syncthreads();
   STAMP(3);
 
   // ---- 2. cells
-  T *Wc = Wb + lc * nd;
-  T *Rc = Rb + lc * nd;
-  for (int base = 0; base < (DBG(1) ? 0 : ncell); base += CH) {
+  const int ncell_eff = DBG(1) ? 0 : ncell;
+  for (int base = 0; base < ncell_eff; base += CH) {
     const bool act = (tid < CH * P) && (base + lc < ncell);
     const int nxt = base + CH;
-    const bool act_next = (tid < CH * P) && (nxt + lc < ncell);
+    const bool has_next = nxt < ncell;
+    const int cnt_next = has_next ? ((ncell - nxt < CH ? ncell - nxt : CH) * nd) : 0;
+    if (has_next && !DBG(8)) prefetch(c0 + nxt, cnt_next);
+    const T *cf = Cb + lc * nd;
+    const uint16_t *lm = Lb + lc * nd;
     unsigned mask = 0;
     bool any_mask = false;
     if (HN) {
@@ -265,13 +293,12 @@ apply_batches(const ApplyArgs<T> A, const Tables<T, n> tab) {
     if (act) {
 #pragma unroll
       for (int i = 0; i < n; ++i) {
-        ix[i] = L.ix[i];
-        iz[i] = L.iz[i];
+        ix[i] = lm[bx + i];
+        iz[i] = lm[bl + i * sl];
       }
 #pragma unroll
       for (int i = 0; i < n; ++i) u[i] = usrc[ix[i]];
     }
-    if (act_next) load_idx(nxt);  // index map of the next chunk: needed right at its start
 
     if (dim == 3) {
       if (HN && any_mask) {
@@ -312,10 +339,11 @@ apply_batches(const ApplyArgs<T> A, const Tables<T, n> tab) {
       // P2: interpolate along z -> values at quadrature points; z-derivative part
       if (act) {
         lds_load<n>(Wc + bz, n2, u);
+        lds_load<n>(cf + bz, n2, v);
         mvt<n, 1>(tab.S, u, w);
         mv<n, -1>(tab.Dt, w, g);
 #pragma unroll
-        for (int s = 0; s < n; ++s) g[s] *= L.cz[s];
+        for (int s = 0; s < n; ++s) g[s] *= v[s];
         mvt<n, -1>(tab.Dt, g, r);
         lds_store<n>(Wc + bz, n2, w);
         lds_store<n>(Rc + bz, n2, r);
@@ -324,9 +352,10 @@ apply_batches(const ApplyArgs<T> A, const Tables<T, n> tab) {
       // P3: y-derivative part
       if (act) {
         lds_load<n>(Wc + by, n, w);
+        lds_load<n>(cf + by, n, v);
         mv<n, -1>(tab.Dt, w, g);
 #pragma unroll
-        for (int s = 0; s < n; ++s) g[s] *= L.cy[s];
+        for (int s = 0; s < n; ++s) g[s] *= v[s];
         mvt<n, -1>(tab.Dt, g, r);
         lds_load<n>(Rc + by, n, v);
 #pragma unroll
@@ -337,9 +366,10 @@ apply_batches(const ApplyArgs<T> A, const Tables<T, n> tab) {
       // P4: x-derivative part, then S^T along x
       if (act) {
         lds_load<n>(Wc + bx, 1, w);
+        lds_load<n>(cf + bx, 1, v);
         mv<n, -1>(tab.Dt, w, g);
 #pragma unroll
-        for (int s = 0; s < n; ++s) g[s] *= L.cx[s];
+        for (int s = 0; s < n; ++s) g[s] *= v[s];
         mvt<n, -1>(tab.Dt, g, r);
         lds_load<n>(Rc + bx, 1, v);
 #pragma unroll
@@ -347,14 +377,15 @@ apply_batches(const ApplyArgs<T> A, const Tables<T, n> tab) {
         mv<n, 1>(tab.S, r, v);
         lds_store<n>(Rc + bx, 1, v);
       }
-      if (act_next && !DBG(8)) load_coef(nxt);  // this chunk's coefficients are consumed
       __syncthreads();
-      // P5: S^T along y
+      // P5: S^T along y; coefficient / index buffers are free now (last read in P4 / at the chunk
+      // start): stage the next chunk
       if (act) {
         lds_load<n>(Rc + by, n, u);
         mv<n, 1>(tab.S, u, v);
         lds_store<n>(Rc + by, n, v);
       }
+      if (has_next) stage(cnt_next);
       __syncthreads();
       // P6: S^T along z, scatter-add into the batch accumulator
       if (act) {
@@ -411,10 +442,11 @@ apply_batches(const ApplyArgs<T> A, const Tables<T, n> tab) {
       // P1: interpolate along y; y-derivative part
       if (act) {
         lds_load<n>(Wc + by, n, u);
+        lds_load<n>(cf + by, n, v);
         mvt<n, 1>(tab.S, u, w);
         mv<n, -1>(tab.Dt, w, g);
 #pragma unroll
-        for (int s = 0; s < n; ++s) g[s] *= L.cy[s];
+        for (int s = 0; s < n; ++s) g[s] *= v[s];
         mvt<n, -1>(tab.Dt, g, r);
         lds_store<n>(Wc + by, n, w);
         lds_store<n>(Rc + by, n, r);
@@ -423,9 +455,10 @@ apply_batches(const ApplyArgs<T> A, const Tables<T, n> tab) {
       // P2: x-derivative part, S^T along x
       if (act) {
         lds_load<n>(Wc + bx, 1, w);
+        lds_load<n>(cf + bx, 1, v);
         mv<n, -1>(tab.Dt, w, g);
 #pragma unroll
-        for (int s = 0; s < n; ++s) g[s] *= L.cx[s];
+        for (int s = 0; s < n; ++s) g[s] *= v[s];
         mvt<n, -1>(tab.Dt, g, r);
         lds_load<n>(Rc + bx, 1, v);
 #pragma unroll
@@ -433,7 +466,6 @@ apply_batches(const ApplyArgs<T> A, const Tables<T, n> tab) {
         mv<n, 1>(tab.S, r, v);
         lds_store<n>(Rc + bx, 1, v);
       }
-      if (act_next && !DBG(8)) load_coef(nxt);
       __syncthreads();
       // P3: S^T along y, scatter-add
       if (act) {
@@ -457,6 +489,10 @@ apply_batches(const ApplyArgs<T> A, const Tables<T, n> tab) {
 #pragma unroll
         for (int k = 0; k < n; ++k) lds_add(&acc[iz[k]], v[k]);
       }
+      if (has_next) {
+        stage(cnt_next);  // Cb last read in P2, Lb at the chunk start
+        __syncthreads();
+      }
     }
     // Wc is next written in P0 of the following chunk and was last read in P4 (P2 in 2D); Rc is next
     // written in P2 (P1) and was last read before the scatter-add: both separated by barriers.
@@ -466,61 +502,48 @@ apply_batches(const ApplyArgs<T> A, const Tables<T, n> tab) {
   STAMP(13);
 
   // ---- 4. scatter (distribute_local_to_global fee_gpu.cuh:346-363 + identity rows
-  //         constraint_handler_gpu.cu:276-289), one write per batch dof
+  //         constraint_handler_gpu.cu:276-289), one write per batch dof.  The dof list is re-read
+  //         (L2 hit) rather than kept in 9 VGPRs across the cell loop.
+  uint32_t G[kGU];
+  uint8_t F[kGU];
+  load_dofs(d0, nb, G, F);
   if (TWOPASS) {
     // batch dofs are ordered [interior | shared]: interior dofs belong to this batch alone and are
     // final; partial sums of shared dofs go to the batch's contiguous halo slots (reduce_shared)
-    T *halo = A.halo + A.halo_off[b];
-    for (int t0 = 0; t0 < (DBG(4) ? 0 : nb); t0 += kGU * kBlock) {
-      uint32_t g[kGU];
+    T *halo = A.halo + hoff;
+    if (!DBG(4)) {
       T old[kGU];
-#pragma unroll
-      for (int j = 0; j < kGU; ++j) {
-        const int t = t0 + tid + j * kBlock;
-        g[j] = A.bdofs[d0 + (t < nb ? t : nb - 1)];
-      }
       if (A.add) {  // uniform branch
 #pragma unroll
-        for (int j = 0; j < kGU; ++j) old[j] = A.dst[g[j] & 0x7fffffffu];
+        for (int j = 0; j < kGU; ++j) old[j] = A.dst[G[j] & 0x7fffffffu];
       }
 #pragma unroll
       for (int j = 0; j < kGU; ++j) {
-        const int t = t0 + tid + j * kBlock;
+        const int t = tid + j * kBlock;
         if (t < nint) {
-          if (!(g[j] >> 31)) A.dst[g[j]] = A.add ? old[j] + acc[t] : acc[t];
+          if (!(G[j] >> 31)) A.dst[G[j]] = A.add ? old[j] + acc[t] : acc[t];
         } else if (t < nb) {
           halo[t - nint] = acc[t];  // constrained shared dofs: value ignored by reduce_shared
         }
       }
     }
-  } else {
-    for (int t0 = 0; t0 < (DBG(4) ? 0 : nb); t0 += kGU * kBlock) {
-      uint32_t g[kGU];
-      uint8_t f[kGU];
-      T old[kGU];
+  } else if (!DBG(4)) {
+    // later colours (and vmult_add) read-modify-write; the read is unconditional to keep the loads
+    // free of per-element branches
+    T old[kGU];
 #pragma unroll
-      for (int j = 0; j < kGU; ++j) {
-        const int t = t0 + tid + j * kBlock;
-        const int tc = t < nb ? t : nb - 1;
-        g[j] = A.bdofs[d0 + tc];
-        f[j] = A.bflags[d0 + tc];
-      }
-      // later colours (and vmult_add) read-modify-write; the read is unconditional to keep the loads
-      // free of per-element branches
+    for (int j = 0; j < kGU; ++j) old[j] = A.dst[G[j] & 0x7fffffffu];
 #pragma unroll
-      for (int j = 0; j < kGU; ++j) old[j] = A.dst[g[j] & 0x7fffffffu];
-#pragma unroll
-      for (int j = 0; j < kGU; ++j) {
-        const int t = t0 + tid + j * kBlock;
-        if (t < nb && !(g[j] >> 31))
-          A.dst[g[j]] = ((f[j] & kFlagAdd) || A.add) ? old[j] + acc[t] : acc[t];
-      }
+    for (int j = 0; j < kGU; ++j) {
+      const int t = tid + j * kBlock;
+      if (t < nb && !(G[j] >> 31)) A.dst[G[j]] = ((F[j] & kFlagAdd) || A.add) ? old[j] + acc[t] : acc[t];
     }
   }
-#ifdef MFGPU_STAMPS
-  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-#endif
   STAMP(15);
+  if (!has_nb) break;
+  __syncthreads();  // usrc / acc are rewritten for the next batch
+  b = bn;
+  }  // batch loop
 }
 
 // Second pass of the two-pass mode: one thread per shared dof sums the partial sums the touching
@@ -598,47 +621,64 @@ __global__ void fill_kernel(T *v, size_t n, T a) {
 // ---------------------------------------------------------------------------------------------
 
 template <int dim, int n, typename T>
-static size_t lds_bytes_t(uint32_t nb_max) {
+static size_t lds_bytes_t(uint32_t nb_max, int kBlock) {
   constexpr int nd = (dim == 3) ? n * n * n : n * n;
-  constexpr int CH = kBlock / (nd / n);
-  return (size_t)(2 * nb_max + 2 * CH * nd + n * n) * sizeof(T);
+  const int CH = kBlock / (nd / n);
+  return (size_t)(2 * nb_max + 3 * CH * nd + n * n) * sizeof(T) + (size_t)CH * nd * sizeof(uint16_t);
 }
+
+template <int dim, int n, typename T, bool HN, bool TP, int KB>
+static hipError_t launch_k(const ApplyArgs<T> &a, const Tables<T, n> &tab, size_t lds, uint32_t grid, hipStream_t st) {
+  hipLaunchKernelGGL((apply_batches<dim, n, T, HN, TP, KB>), dim3(grid), dim3(KB), lds, st, a, tab);
+  return hipGetLastError();
+}
+
+// dispatch over the run-time switches (hanging nodes, scatter mode, workgroup size)
+#define MFGPU_SWITCH(FN, ...)                                                       \
+  (kb == 512 ? (hn ? (twopass ? FN<dim, n, T, true, true, 512>(__VA_ARGS__)          \
+                              : FN<dim, n, T, true, false, 512>(__VA_ARGS__))        \
+                   : (twopass ? FN<dim, n, T, false, true, 512>(__VA_ARGS__)         \
+                              : FN<dim, n, T, false, false, 512>(__VA_ARGS__)))      \
+             : (hn ? (twopass ? FN<dim, n, T, true, true, 256>(__VA_ARGS__)          \
+                              : FN<dim, n, T, true, false, 256>(__VA_ARGS__))        \
+                   : (twopass ? FN<dim, n, T, false, true, 256>(__VA_ARGS__)         \
+                              : FN<dim, n, T, false, false, 256>(__VA_ARGS__))))
 
 template <int dim, int n, typename T>
 static hipError_t launch_t(const ApplyArgs<T> &a, const double *S, const double *Dt, bool hn,
-                           bool twopass, uint32_t nbatches, hipStream_t st) {
+                           bool twopass, int kb, uint32_t grid, hipStream_t st) {
   Tables<T, n> tab;
   for (int i = 0; i < ((n + 1) / 2) * n; ++i) {
     tab.S[i] = (T)S[i];
     tab.Dt[i] = (T)Dt[i];
   }
-
-  const size_t lds = lds_bytes_t<dim, n, T>(a.nb_max);
-  if (hn && twopass)
-    hipLaunchKernelGGL((apply_batches<dim, n, T, true, true>), dim3(nbatches), dim3(kBlock), lds, st, a, tab);
-  else if (hn)
-    hipLaunchKernelGGL((apply_batches<dim, n, T, true, false>), dim3(nbatches), dim3(kBlock), lds, st, a, tab);
-  else if (twopass)
-    hipLaunchKernelGGL((apply_batches<dim, n, T, false, true>), dim3(nbatches), dim3(kBlock), lds, st, a, tab);
-  else
-    hipLaunchKernelGGL((apply_batches<dim, n, T, false, false>), dim3(nbatches), dim3(kBlock), lds, st, a, tab);
-  return hipGetLastError();
+  const size_t lds = lds_bytes_t<dim, n, T>(a.nb_max, kb);
+  return MFGPU_SWITCH(launch_k, a, tab, lds, grid, st);
 }
 
+template <int dim, int n, typename T, bool HN, bool TP, int KB>
+static hipError_t configure_k(size_t lds) {
+  return hipFuncSetAttribute((const void *)apply_batches<dim, n, T, HN, TP, KB>,
+                             hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+}
 template <int dim, int n, typename T>
-static hipError_t configure_t(size_t lds) {
-  hipError_t e = hipFuncSetAttribute((const void *)apply_batches<dim, n, T, true, true>,
-                                     hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-  if (e == hipSuccess)
-    e = hipFuncSetAttribute((const void *)apply_batches<dim, n, T, true, false>,
-                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-  if (e == hipSuccess)
-    e = hipFuncSetAttribute((const void *)apply_batches<dim, n, T, false, true>,
-                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-  if (e == hipSuccess)
-    e = hipFuncSetAttribute((const void *)apply_batches<dim, n, T, false, false>,
-                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+static hipError_t configure_t(size_t lds, int kb) {
+  hipError_t e = hipSuccess;
+  for (int hn_ = 0; hn_ < 2 && e == hipSuccess; ++hn_)
+    for (int tp_ = 0; tp_ < 2 && e == hipSuccess; ++tp_) {
+      const bool hn = hn_, twopass = tp_;
+      e = MFGPU_SWITCH(configure_k, lds);
+    }
   return e;
+}
+
+template <int dim, int n, typename T, bool HN, bool TP, int KB>
+static hipError_t occupancy_k(size_t lds, int *blocks) {
+  return hipOccupancyMaxActiveBlocksPerMultiprocessor(blocks, apply_batches<dim, n, T, HN, TP, KB>, KB, lds);
+}
+template <int dim, int n, typename T>
+static hipError_t occupancy_t(bool hn, bool twopass, int kb, size_t lds, int *blocks) {
+  return MFGPU_SWITCH(occupancy_k, lds, blocks);
 }
 
 #define MFGPU_DISPATCH(CALL)                                \
@@ -659,8 +699,8 @@ static hipError_t configure_t(size_t lds) {
   }
 
 template <typename T>
-size_t apply_lds_bytes(int dim, int n, uint32_t nb_max) {
-#define CALL(D, N) lds_bytes_t<D, N, T>(nb_max)
+size_t apply_lds_bytes(int dim, int n, uint32_t nb_max, int kb) {
+#define CALL(D, N) lds_bytes_t<D, N, T>(nb_max, kb)
   switch (dim * 10 + n) {
     case 22: return CALL(2, 2);
     case 23: return CALL(2, 3);
@@ -680,16 +720,23 @@ size_t apply_lds_bytes(int dim, int n, uint32_t nb_max) {
 }
 
 template <typename T>
-hipError_t apply_configure(int dim, int n, size_t lds) {
-#define CALL(D, N) configure_t<D, N, T>(lds)
+hipError_t apply_configure(int dim, int n, size_t lds, int kb) {
+#define CALL(D, N) configure_t<D, N, T>(lds, kb)
+  MFGPU_DISPATCH(CALL)
+#undef CALL
+}
+
+template <typename T>
+hipError_t apply_occupancy(int dim, int n, bool hn, bool twopass, int kb, size_t lds, int *blocks) {
+#define CALL(D, N) occupancy_t<D, N, T>(hn, twopass, kb, lds, blocks)
   MFGPU_DISPATCH(CALL)
 #undef CALL
 }
 
 template <typename T>
 hipError_t apply_launch(int dim, int n, const ApplyArgs<T> &a, const double *S, const double *Dt,
-                        bool hn, bool twopass, uint32_t nbatches, hipStream_t st) {
-#define CALL(D, N) launch_t<D, N, T>(a, S, Dt, hn, twopass, nbatches, st)
+                        bool hn, bool twopass, int kb, uint32_t grid, hipStream_t st) {
+#define CALL(D, N) launch_t<D, N, T>(a, S, Dt, hn, twopass, kb, grid, st)
   MFGPU_DISPATCH(CALL)
 #undef CALL
 }
@@ -740,10 +787,11 @@ hipError_t fill_launch(T *v, size_t n, T a, hipStream_t st) {
 }
 
 #define INST(T)                                                                                         \
-  template size_t apply_lds_bytes<T>(int, int, uint32_t);                                               \
-  template hipError_t apply_configure<T>(int, int, size_t);                                             \
+  template size_t apply_lds_bytes<T>(int, int, uint32_t, int);                                          \
+  template hipError_t apply_configure<T>(int, int, size_t, int);                                        \
+  template hipError_t apply_occupancy<T>(int, int, bool, bool, int, size_t, int *);                     \
   template hipError_t apply_launch<T>(int, int, const ApplyArgs<T> &, const double *, const double *,   \
-                                      bool, bool, uint32_t, hipStream_t);                               \
+                                      bool, bool, int, uint32_t, hipStream_t);                          \
   template hipError_t reduce_launch<T>(T *, const T *, const T *, const uint32_t *, const uint32_t *,   \
                                        const uint32_t *, uint32_t, int, hipStream_t);                   \
   template hipError_t orphan_launch<T>(T *, const T *, const uint32_t *, uint32_t, int, hipStream_t);   \

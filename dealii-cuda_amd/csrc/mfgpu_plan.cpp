@@ -61,7 +61,8 @@ int derive_tables(int n, const double *sv, const double *sg, std::vector<double>
 static void default_batch_limits(const mfgpu_desc &d, uint32_t &max_cells, uint32_t &max_dofs) {
   const int p = d.degree, dim = d.dim;
   max_dofs = d.max_dofs_per_batch ? d.max_dofs_per_batch : 2304u;
-  if (max_dofs > 65535u) max_dofs = 65535u;  // lmap is 16 bit
+  // the kernel keeps a batch's dof list and source values in registers: kGU * kBlock = 9 * 256 dofs
+  if (max_dofs > 2304u) max_dofs = 2304u;
   const uint32_t nd = (uint32_t)ipow(p + 1, dim);
   if (max_dofs < nd) max_dofs = nd;
   if (d.max_cells_per_batch) {

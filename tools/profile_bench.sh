@@ -1,0 +1,16 @@
+#!/bin/bash
+# Round profile of the default bench command (run on the GPU box via gpurun):
+#   kernel trace + stats, and separate PMC passes for HBM traffic (FETCH_SIZE / WRITE_SIZE cannot
+#   share a pass: MI355X_MICROARCH.md, rocprofv3 PMC slots).  Summaries are copied to profiles/.
+# usage: tools/profile_bench.sh TAG [bench args]
+cd /tmp && export TMPDIR=/tmp
+R=${GRAFT_REPO_ROOT:-/root/repo}
+TAG=${1:-r01}; shift
+O=$R/gpurun_out/$TAG
+mkdir -p $O
+B="python3 $R/bench.py --steps 20 --warmup 3 --no-cpu $@"
+timeout -k 5 300 rocprofv3 --kernel-trace --stats --output-format csv -d $O/kt -- $B > $O/kt.log 2>&1; echo "kt rc=$?"
+timeout -k 5 300 rocprofv3 --pmc FETCH_SIZE --output-format csv -d $O/fetch -- $B > $O/fetch.log 2>&1; echo "fetch rc=$?"
+timeout -k 5 300 rocprofv3 --pmc WRITE_SIZE --output-format csv -d $O/write -- $B > $O/write.log 2>&1; echo "write rc=$?"
+timeout -k 5 300 rocprofv3 --pmc TCC_HIT_sum TCC_MISS_sum --output-format csv -d $O/l2 -- $B > $O/l2.log 2>&1; echo "l2 rc=$?"
+python3 $R/tools/profile_summary.py $O $R/gpurun_out/${TAG}_summary
