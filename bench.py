@@ -79,6 +79,8 @@ def main():
     ap.add_argument("--batch-cells", type=int, default=0)
     ap.add_argument("--batch-dofs", type=int, default=0)
     ap.add_argument("--colored", action="store_true", help="coloured-scatter mode instead of two-pass")
+    ap.add_argument("--adaptive", type=int, default=0, metavar="NREF",
+                    help="configs[2]: bmop -DADAPTIVE_GRID mesh with hanging nodes instead of the uniform cube (1 GPU)")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -100,7 +102,12 @@ def main():
     p = args.degree
     n_glob = int(round(args.cells * world ** (1.0 / 3.0)))
     zb, ze = slab_ranges(n_glob, world)[rank]
-    mesh = mf.Mesh.uniform(3, p, n_glob, slab=(zb, ze), number_type=nt)
+    if args.adaptive:
+        if world != 1:
+            raise SystemExit("--adaptive is a single-GPU configuration")
+        mesh = mf.Mesh.adaptive(3, p, args.adaptive, number_type=nt)
+    else:
+        mesh = mf.Mesh.uniform(3, p, n_glob, slab=(zb, ze), number_type=nt)
     mesh.desc.max_cells_per_batch = args.batch_cells
     mesh.desc.max_dofs_per_batch = args.batch_dofs
     if args.colored:
@@ -111,6 +118,8 @@ def main():
     nd = (p + 1) ** 3
     n_dofs_glob = (p * n_glob + 1) ** 3
     n_cells_glob = n_glob ** 3
+    if args.adaptive:
+        n_dofs_glob, n_cells_glob = mesh.n_dofs, mesh.n_cells
 
     dst = torch.full((N_loc,), 0.1, device=dev, dtype=tdt)  # bmop.cu:140
     src = torch.zeros(N_loc, device=dev, dtype=tdt)
@@ -171,7 +180,8 @@ def main():
     if os.path.exists(tj):
         try:
             tr = json.load(open(tj))
-            if tr.get("workload") == f"p{p}_3d_n{n_glob}_{'f32' if args.float else 'f64'}" and world == 1:
+            if (tr.get("workload") == f"p{p}_3d_n{n_glob}_{'f32' if args.float else 'f64'}" and world == 1
+                    and not args.adaptive and not args.colored and not args.batch_cells and not args.batch_dofs):
                 traffic = tr["hbm_bytes_per_launch"]
         except Exception:
             traffic = None
@@ -189,8 +199,10 @@ def main():
         "vs_baseline": None,
         "dtype": "f32" if args.float else "f64",
         "data": "synthetic",
-        "config": {"workload": f"bmop: DEGREE_FE={p}, DIMENSION=3, MATRIX_FREE_UNIFORM_MESH, hyper_cube(-1,1), "
-                               f"{n_glob}^3 cells, {n_dofs_glob} DoFs, {world} z-slab(s)",
+        "config": {"workload": (f"bmop: DEGREE_FE={p}, DIMENSION=3, ADAPTIVE_GRID n_ref={args.adaptive}, hanging nodes, "
+                                f"{n_cells_glob} cells, {n_dofs_glob} DoFs") if args.adaptive else
+                               (f"bmop: DEGREE_FE={p}, DIMENSION=3, MATRIX_FREE_UNIFORM_MESH, hyper_cube(-1,1), "
+                                f"{n_glob}^3 cells, {n_dofs_glob} DoFs, {world} z-slab(s)"),
                    "cells_per_dir": n_glob, "n_dofs": n_dofs_glob, "n_cells": n_cells_glob,
                    "parallelism": f"slab{world}" + (f"/{args.mode}" if world > 1 else ""),
                    "plan": stats, "finite": finite},

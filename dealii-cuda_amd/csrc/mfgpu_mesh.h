@@ -2,6 +2,7 @@
 #ifndef MFGPU_MESH_H
 #define MFGPU_MESH_H
 
+#include <array>
 #include <vector>
 
 #include "mfgpu_internal.h"
@@ -21,6 +22,7 @@ struct Mesh {
   std::vector<uint32_t> loc2glob, constraint_mask, constrained;
   std::vector<double> JxW, inv_jac, qpoints, dof_coords;
   std::vector<uint32_t> iface[2];
+  std::vector<uint32_t> cell_levels;  // adaptive meshes: (level, cx, cy, cz) per cell
   // Number-typed copies when number_type == F32
   std::vector<unsigned char> t_JxW, t_inv_jac, t_qpoints, t_sv, t_sg;
 
@@ -31,6 +33,7 @@ struct Mesh {
 
 int build_uniform(Mesh &M, const uint32_t *nper, double lo, double hi, uint32_t sb, uint32_t se);
 int build_adaptive(Mesh &M, int n_ref);
+int build_from_tree_leaves(Mesh &M, int dim, std::vector<std::array<uint32_t, 4>> leaves);
 
 }  // namespace mfgpu
 

@@ -42,7 +42,8 @@ SYMBOLS = [
     "mfgpu_destroy", "mfgpu_last_error", "mfgpu_plan_stats", "mfgpu_profile_enable", "mfgpu_profile_read",
     "mfgpu_plan_create", "mfgpu_plan_destroy", "mfgpu_plan_array_u32", "mfgpu_plan_lmap", "mfgpu_plan_bflags",
     "mfgpu_vec_alloc", "mfgpu_vec_free", "mfgpu_vec_fill", "mfgpu_vec_from_host", "mfgpu_vec_to_host",
-    "mfgpu_device_synchronize", "mfgpu_mesh_create_uniform", "mfgpu_mesh_create_adaptive", "mfgpu_mesh_destroy",
+    "mfgpu_device_synchronize", "mfgpu_mesh_create_uniform", "mfgpu_mesh_create_adaptive", "mfgpu_mesh_create_from_leaves",
+    "mfgpu_mesh_cell_levels", "mfgpu_mesh_destroy",
     "mfgpu_mesh_desc", "mfgpu_mesh_dof_coords", "mfgpu_mesh_interface_dofs",
 ]
 
@@ -86,6 +87,9 @@ def lib():
         L.mfgpu_mesh_create_uniform.argtypes = [C.c_int, C.c_int, C.POINTER(C.c_uint32), C.c_double, C.c_double,
                                                 C.c_uint32, C.c_uint32, C.c_int, C.POINTER(C.c_void_p)]
         L.mfgpu_mesh_create_adaptive.argtypes = [C.c_int, C.c_int, C.c_int, C.c_int, C.POINTER(C.c_void_p)]
+        L.mfgpu_mesh_create_from_leaves.argtypes = [C.c_int, C.c_int, C.c_void_p, C.c_uint32, C.c_int, C.POINTER(C.c_void_p)]
+        L.mfgpu_mesh_cell_levels.argtypes = [C.c_void_p, C.POINTER(C.c_void_p)]
+        L.mfgpu_mesh_cell_levels.restype = C.c_int64
         L.mfgpu_mesh_destroy.argtypes = [C.c_void_p]
         L.mfgpu_mesh_destroy.restype = None
         L.mfgpu_mesh_desc.argtypes = [C.c_void_p, C.POINTER(Desc)]
@@ -136,6 +140,18 @@ class Mesh:
         h = C.c_void_p()
         _check(lib().mfgpu_mesh_create_adaptive(dim, degree, n_ref, number_type, C.byref(h)))
         return cls(h)
+
+    @classmethod
+    def from_leaves(cls, dim, degree, leaves, number_type=F64):
+        lv = np.ascontiguousarray(leaves, dtype=np.uint32).reshape(-1, 4)
+        h = C.c_void_p()
+        _check(lib().mfgpu_mesh_create_from_leaves(dim, degree, lv.ctypes.data, len(lv), number_type, C.byref(h)))
+        return cls(h)
+
+    def cell_levels(self):
+        p = C.c_void_p()
+        cnt = lib().mfgpu_mesh_cell_levels(self._h, C.byref(p))
+        return _view(p.value, cnt, np.uint32).reshape(-1, 4).copy()
 
     def __del__(self):
         if getattr(self, "_h", None):

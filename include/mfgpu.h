@@ -158,6 +158,12 @@ int mfgpu_mesh_create_uniform(int dim, int degree, const uint32_t *n_per_dir, do
 /* bmop_common.h:49-105 pseudo_adaptive_refinement on the cube (ADAPTIVE_GRID), n_ref as in
  * bmop's argv; octree with 2:1 balance and hanging-node constraints.                          */
 int mfgpu_mesh_create_adaptive(int dim, int degree, int n_ref, int number_type, mfgpu_mesh **out);
+/* same setup from an explicit one-irregular set of octree leaves (level, cx, cy, cz) x n_leaves on
+ * hyper_cube(-1,1): lets tests build the awkward small cases of test_hanging_nodes_gpu.cu:297-331 */
+int mfgpu_mesh_create_from_leaves(int dim, int degree, const uint32_t *leaves, uint32_t n_leaves,
+                                  int number_type, mfgpu_mesh **out);
+/* (level, cx, cy, cz) of every cell in mesh order [n_cells*4]; empty for uniform meshes */
+int64_t mfgpu_mesh_cell_levels(const mfgpu_mesh *m, const uint32_t **ptr);
 void mfgpu_mesh_destroy(mfgpu_mesh *m);
 /* fills *desc with pointers into the mesh (valid until mfgpu_mesh_destroy) */
 int mfgpu_mesh_desc(const mfgpu_mesh *m, mfgpu_desc *desc);

@@ -196,3 +196,83 @@ def test_full_size_properties(n):
     # full-mesh rows strictly inside the slab only see slab cells, but src entries at constrained dofs
     # differ (zeroed) identically in both; compare directly
     assert rel(ys[sel], Au[gz0:gz0 + slab.n_dofs][sel]) <= 1e-12
+
+
+def _all_masks(dim):
+    """every mask of the reference's known-answer test (type bits x face bits) + 3D edge masks"""
+    out = []
+    for xyz in range(1, (1 << dim) - 1 + 1):
+        for t in range(1 << dim):
+            out.append(t | (xyz << 3))
+    if dim == 3:
+        for e in (1 << 6, 1 << 7, 1 << 8, (1 << 6) | (1 << 5), (1 << 7) | (1 << 3), (1 << 8) | (1 << 4)):
+            for t in range(8):
+                out.append(e | t)
+    return out
+
+
+@pytest.mark.parametrize("dim,p,n", [(2, 1, 8), (2, 2, 8), (2, 4, 8), (3, 1, 5), (3, 2, 4), (3, 3, 4), (3, 4, 4), (3, 5, 3)])
+@pytest.mark.parametrize("colored", [False, True])
+def test_hanging_node_stages_synthetic_masks(dim, p, n, colored):
+    """in-kernel resolve_hanging_nodes (NOTRANSPOSE before evaluate, TRANSPOSE after integrate,
+    fee_gpu.cuh:333-335,349-351) against the oracle's emulation for every mask type.  The masks are
+    assigned to cells of a conforming mesh: algebraically A = sum_cells P^T C^T K C P either way."""
+    od = o.uniform_mesh_desc(dim, p, n)
+    masks = _all_masks(dim)
+    rng = np.random.default_rng(5)
+    cm = np.zeros(od.n_cells, dtype=np.uint32)
+    pick = rng.permutation(od.n_cells)[:min(od.n_cells * 2 // 3, 4 * len(masks))]
+    cm[pick] = np.array(masks, dtype=np.uint32)[np.arange(len(pick)) % len(masks)]
+    od.constraint_mask = cm
+    x = rng.standard_normal(od.n_dofs)
+    ref = o.vmult(od, x)
+    desc, keep = desc_from_oracle(od, colored=colored)
+    op = mf.Operator(desc, keep)
+    assert rel(gpu_vmult(op, x), ref) <= 1e-12
+    # and the assembled C^T K C form
+    assert rel(ref, o.assemble(od) @ x) <= 1e-12
+
+
+@pytest.mark.parametrize("dim,p,nref", [(2, 2, 4), (2, 4, 5), (3, 1, 4), (3, 2, 4), (3, 4, 4), (3, 4, 5), (3, 3, 5)])
+@pytest.mark.parametrize("colored", [False, True])
+def test_adaptive_mesh_with_hanging_nodes(dim, p, nref, colored):
+    """BASELINE configs[2]: bmop -DADAPTIVE_GRID recipe (bmop_common.h:49-105) with hanging-node
+    constraints handled in the kernel; GPU vs the oracle's emulation of the reference GPU path."""
+    mesh = mf.Mesh.adaptive(dim, p, nref)
+    assert (mesh.arrays()["constraint_mask"] != 0).any()
+    od = oracle_desc_from_mesh(mesh)
+    if colored:
+        mesh.desc.flags |= mf.COLORED_SCATTER
+    op = mf.Operator(mesh.desc, mesh)
+    assert op.plan_stats()["n_orphans"] > 0  # the hanging dofs
+    rng = np.random.default_rng(dim + p + nref)
+    x = rng.standard_normal(mesh.n_dofs)
+    assert rel(gpu_vmult(op, x), o.vmult(od, x)) <= 1e-12
+    y0 = rng.standard_normal(mesh.n_dofs)
+    assert rel(gpu_vmult(op, x, y0=y0), o.vmult_add(od, y0, x)) <= 1e-12
+
+
+def test_adaptive_float():
+    mesh = mf.Mesh.adaptive(3, 4, 4, number_type=mf.F32)
+    od = oracle_desc_from_mesh(mesh, dtype=np.float64)
+    op = mf.Operator(mesh.desc, mesh)
+    x = np.random.default_rng(9).standard_normal(mesh.n_dofs).astype(np.float32)
+    assert rel(gpu_vmult(op, x, mf.F32), o.vmult(od, x.astype(np.float64))) <= 1e-5
+
+
+def test_adaptive_full_size_properties():
+    """configs[2] at the reference's scale (n_ref = 6): linearity, symmetry, identity rows"""
+    mesh = mf.Mesh.adaptive(3, 4, 6)
+    N = mesh.n_dofs
+    op = mf.Operator(mesh.desc, mesh)
+    con = mesh.arrays()["constrained_dofs"]
+    rng = np.random.default_rng(0)
+    u, v = rng.standard_normal(N), rng.standard_normal(N)
+    Au, Av = gpu_vmult(op, u), gpu_vmult(op, v)
+    np.testing.assert_array_equal(Au[con], u[con])
+    uf, vf = u.copy(), v.copy()
+    uf[con] = 0
+    vf[con] = 0
+    Auf, Avf = gpu_vmult(op, uf), gpu_vmult(op, vf)
+    assert abs(vf @ Auf - uf @ Avf) <= 1e-11 * abs(vf @ Auf)
+    assert rel(gpu_vmult(op, 0.5 * u + 2.0 * v), 0.5 * Au + 2.0 * Av) <= 1e-12
