@@ -276,3 +276,21 @@ def test_adaptive_full_size_properties():
     Auf, Avf = gpu_vmult(op, uf), gpu_vmult(op, vf)
     assert abs(vf @ Auf - uf @ Avf) <= 1e-11 * abs(vf @ Auf)
     assert rel(gpu_vmult(op, 0.5 * u + 2.0 * v), 0.5 * Au + 2.0 * Av) <= 1e-12
+
+
+def test_bmop_driver_binaries():
+    """C++ shim + bmop driver (dealii-cuda_amd/host): same CLI and TSV line as reference bmop.cu:152,186-192.
+    C1 plumbing config: DEGREE_FE=2, DIMENSION=2, 5 global refinements -> 4225 dofs."""
+    import subprocess
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    b = os.path.join(root, "dealii-cuda_amd", "host", "bin")
+    out = subprocess.run([os.path.join(b, "bmop-2d-p2"), "5", "4"], capture_output=True, text=True, timeout=120)
+    assert out.returncode == 0, out.stderr
+    lines = [ln.split("\t") for ln in out.stdout.strip().splitlines()]
+    assert [ln[:3] for ln in lines] == [["2", "2", "1089"], ["2", "2", "4225"]]
+    assert all(float(ln[3]) > 0 for ln in lines)
+    out = subprocess.run([os.path.join(b, "bmop-3d-p4"), "4", "4"], capture_output=True, text=True, timeout=120)
+    assert out.returncode == 0 and out.stdout.split("\t")[:3] == ["3", "4", str(65 ** 3)]
+    out = subprocess.run([os.path.join(b, "bmop-3d-p4-adaptive"), "4", "4"], capture_output=True, text=True, timeout=120)
+    assert out.returncode == 0 and out.stdout.split("\t")[:2] == ["3", "4"]
