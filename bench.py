@@ -74,7 +74,7 @@ def main():
     ap.add_argument("--cells", type=int, default=54, help="cells per direction at N=1")
     ap.add_argument("--cpu-cells", type=int, default=32, help="cells per direction of the CPU sample")
     ap.add_argument("--float", action="store_true", help="BMOP_USE_FLOATS")
-    ap.add_argument("--mode", default="pair", choices=["pair", "allreduce"])
+    ap.add_argument("--mode", default="p2p", choices=["p2p", "pair", "allreduce"])
     ap.add_argument("--no-cpu", action="store_true")
     ap.add_argument("--batch-cells", type=int, default=0)
     ap.add_argument("--batch-dofs", type=int, default=0)

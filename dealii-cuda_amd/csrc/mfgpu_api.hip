@@ -40,7 +40,8 @@ struct mfgpu_handle {
   unsigned long long *d_stamps = nullptr;  // diagnostic build only
   size_t lds = 0, device_bytes = 0;
   uint32_t max_grid = 0;  // resident workgroups of the cell-loop kernel
-  int kb = 256;           // threads per workgroup of the cell-loop kernel
+  int stagger = 0;        // see apply_batches
+  bool wave = false;      // wave-granular cell phase (apply_batches<..., WAVE = true>)
   // profiling
   bool prof = false;
   std::vector<hipEvent_t> ev;  // start/stop pairs
@@ -162,22 +163,21 @@ int create_typed(mfgpu_handle *h, const mfgpu_desc &d) {
     set_error(std::string("coefficient fold: ") + hipGetErrorString(e));
     return MFGPU_EHIP;
   }
-  h->kb = 256;
-  if (const char *e = getenv("MFGPU_THREADS")) h->kb = atoi(e) == 512 ? 512 : 256;
-  h->lds = apply_lds_bytes<T>(P.dim, P.n, P.max_batch_dofs, h->kb);
+  h->lds = apply_lds_bytes<T>(P.dim, P.n, P.max_batch_dofs, h->wave);
   if (h->lds > 160 * 1024) {
     set_error("batch needs more than 160 KiB of LDS; lower max_dofs_per_batch");
     return MFGPU_EINVAL;
   }
-  HIP_TRY(apply_configure<T>(P.dim, P.n, h->lds, h->kb));
+  HIP_TRY(apply_configure<T>(P.dim, P.n, h->lds, h->wave));
   // persistent grid: as many workgroups as fit on the chip (each loops over its batches)
   int per_cu = 0, dev = 0;
   hipDeviceProp_t prop;
-  HIP_TRY(apply_occupancy<T>(P.dim, P.n, h->hn, h->twopass, h->kb, h->lds, &per_cu));
+  HIP_TRY(apply_occupancy<T>(P.dim, P.n, h->hn, h->twopass, h->wave, h->lds, &per_cu));
   HIP_TRY(hipGetDevice(&dev));
   HIP_TRY(hipGetDeviceProperties(&prop, dev));
   if (per_cu < 1) per_cu = 1;
   h->max_grid = (uint32_t)per_cu * (uint32_t)prop.multiProcessorCount;
+  if (const char *e = getenv("MFGPU_STAGGER")) h->stagger = atoi(e);
   if (const char *e = getenv("MFGPU_GRID"))
     if (atoi(e) > 0) h->max_grid = (uint32_t)atoi(e);  // tuning experiments only
   return 0;
@@ -202,6 +202,7 @@ int vmult_typed(mfgpu_handle *h, void *dst, const void *src, hipStream_t st, int
   a.src = (const T *)src;
   a.nb_max = P.max_batch_dofs;
   a.add = add;
+  a.stagger = h->stagger;
   a.stamps = h->d_stamps;
   a.dbg = 0;
 #ifdef MFGPU_STAMPS
@@ -225,7 +226,7 @@ int vmult_typed(mfgpu_handle *h, void *dst, const void *src, hipStream_t st, int
       HIP_TRY(hipEventRecord(h->ev[h->ev_used], st));
     }
     a.batch_end = a.batch0 + nbat;
-    HIP_TRY(apply_launch<T>(P.dim, P.n, a, h->S.data(), h->Dt.data(), h->hn, h->twopass, h->kb,
+    HIP_TRY(apply_launch<T>(P.dim, P.n, a, h->S.data(), h->Dt.data(), h->hn, h->twopass, h->wave,
                             nbat < h->max_grid ? nbat : h->max_grid, st));
     if (h->prof) {
       HIP_TRY(hipEventRecord(h->ev[h->ev_used + 1], st));
@@ -270,7 +271,13 @@ int mfgpu_create(const mfgpu_desc *desc, mfgpu_handle **out) {
     return MFGPU_EINVAL;
   }
   mfgpu_handle *h = new mfgpu_handle();
-  int rc = build_plan(d, h->plan);
+  mfgpu_desc dplan = d;
+  if (const char *e = getenv("MFGPU_WAVE")) h->wave = atoi(e) != 0;  // tuning experiments
+  if (h->wave) {  // one wave per batch: smaller batches (<= 768 dofs pass through 64 x 12 registers)
+    if (!dplan.max_dofs_per_batch || dplan.max_dofs_per_batch > 768) dplan.max_dofs_per_batch = 768;
+    if (!dplan.max_cells_per_batch) dplan.max_cells_per_batch = 8;
+  }
+  int rc = build_plan(dplan, h->plan);
   if (rc) {
     delete h;
     return rc;

@@ -27,6 +27,7 @@ struct ApplyArgs {
   uint32_t batch_end;  // one past the last batch of this launch
   uint32_t nb_max;  // LDS layout: max dofs per batch
   int add;          // vmult_add semantics
+  int stagger;      // start delay per resident-workgroup slot of a CU, in units of 8128 cycles
   unsigned long long *stamps;  // diagnostic build only (MFGPU_STAMPS), else nullptr
   int dbg;                     // diagnostic build only: ablation bits (1 cells, 2 gather, 4 scatter, 8 prefetch)
 };
@@ -39,14 +40,14 @@ struct Tables {
 };
 
 template <typename T>
-size_t apply_lds_bytes(int dim, int n, uint32_t nb_max, int kb);
+size_t apply_lds_bytes(int dim, int n, uint32_t nb_max, bool wave);
 template <typename T>
-hipError_t apply_configure(int dim, int n, size_t lds, int kb);
+hipError_t apply_configure(int dim, int n, size_t lds, bool wave);
 template <typename T>
 hipError_t apply_launch(int dim, int n, const ApplyArgs<T> &a, const double *S, const double *Dt,
-                        bool hn, bool twopass, int kb, uint32_t grid, hipStream_t st);
+                        bool hn, bool twopass, bool wave, uint32_t grid, hipStream_t st);
 template <typename T>
-hipError_t apply_occupancy(int dim, int n, bool hn, bool twopass, int kb, size_t lds, int *blocks);
+hipError_t apply_occupancy(int dim, int n, bool hn, bool twopass, bool wave, size_t lds, int *blocks);
 template <typename T>
 hipError_t reduce_launch(T *dst, const T *src, const T *halo, const uint32_t *sdofs, const uint32_t *s_off,
                          const uint32_t *s_idx, uint32_t ns, int add, hipStream_t st);

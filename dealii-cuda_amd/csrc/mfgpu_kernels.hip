@@ -139,33 +139,294 @@ __device__ __forceinline__ void lds_add(T *p, T v) {
 #define DBG(bit) 0
 #endif
 
-constexpr int kMaxBatchDofs = 2304;  // a batch's dof list and source values live in registers
+// a batch's dof list and source values pass through registers: 9 per thread at 256 threads, 12 at 64
+constexpr int max_batch_dofs(int kBlock) { return kBlock == 256 ? 2304 : 768; }
 
-template <int dim, int n, typename T, bool HN, bool TWOPASS, int kBlock>
-__global__ void __launch_bounds__(kBlock)
+// Synchronisation granularity of the cell pipeline: the transposes between two contraction stages go
+// through LDS; with whole cells owned by ONE wave they need no s_barrier, only program order.
+struct WgSync {
+  __device__ static __forceinline__ void sync() { __syncthreads(); }
+};
+struct WaveSync {
+  __device__ static __forceinline__ void sync() {
+    // LDS instructions of one wave execute in order; this only stops the compiler from moving LDS
+    // accesses of other lanes' data across the stage boundary
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+  }
+};
+
+// The cell kernel for the cells a thread group holds at once: gather from the batch array `usrc`,
+// 4*dim contractions (+ hanging-node passes), add into the batch accumulator `acc`.  A thread owns
+// pencil (pa, pb) of its cell; Wc / Rc / cf / lm point to the cell's scratch, coefficient and index map
+// in LDS.  stage_next() is called once, at the point where cf / lm are no longer needed.
+template <int dim, int n, typename T, bool HN, typename Sync, typename StageNext>
+__device__ __forceinline__ void cell_pipeline(const bool act, const int pa, const int pb, const unsigned mask,
+                                              const bool any_mask, const T *usrc, T *acc, T *Wc, T *Rc,
+                                              const T *cf, const uint16_t *lm, const T *Wl,
+                                              const Tables<T, n> &tab, StageNext &&stage_next,
+                                              const int dbg = 0) {
+  constexpr int n2 = n * n;
+#ifdef MFGPU_STAMPS
+#define PDBG(bit) (dbg & (bit))
+#else
+#define PDBG(bit) 0
+#endif
+  const int bx = (dim == 3) ? n * pa + n2 * pb : n * pa;  // x-pencil, stride 1
+  const int by = (dim == 3) ? pa + n2 * pb : pa;          // y-pencil, stride n
+  const int bz = pa + n * pb;                             // z-pencil, stride n2 (3D only)
+  constexpr int sl = (dim == 3) ? n2 : n;                 // stride of the last direction
+  const int bl = (dim == 3) ? bz : by;                    // pencil base of the last direction
+  T u[n], v[n], w[n], g[n], r[n];
+  uint16_t ix[n], iz[n];
+  if (act) {
+#pragma unroll
+    for (int i = 0; i < n; ++i) {
+      ix[i] = lm[bx + i];
+      iz[i] = lm[bl + i * sl];
+    }
+#pragma unroll
+    for (int i = 0; i < n; ++i) u[i] = PDBG(32) ? T(ix[i]) : usrc[ix[i]];
+  }
+
+  if (dim == 3) {
+    if (HN && any_mask) {
+      // resolve_hanging_nodes_shmem<NOTRANSPOSE>: x, then y, then z (hanging_nodes.cuh:767-777)
+      bool type;
+      if (act) {
+        if (mask && hn_flag3<n, 0>(mask, pa, pb, type)) hn_pencil<n, T, false>(Wl, type, u);
+        lds_store<n>(Wc + bx, 1, u);
+      }
+      Sync::sync();
+      if (act) {
+        lds_load<n>(Wc + by, n, u);
+        if (mask && hn_flag3<n, 1>(mask, pb, pa, type)) hn_pencil<n, T, false>(Wl, type, u);
+        lds_store<n>(Wc + by, n, u);
+      }
+      Sync::sync();
+      if (act) {
+        lds_load<n>(Wc + bz, n2, u);
+        if (mask && hn_flag3<n, 2>(mask, pa, pb, type)) hn_pencil<n, T, false>(Wl, type, u);
+        lds_store<n>(Wc + bz, n2, u);
+      }
+      Sync::sync();
+      if (act) lds_load<n>(Wc + bx, 1, u);  // P0 rewrites the same pencil in place
+    }
+    // P0: interpolate along x
+    if (act) {
+      mvt<n, 1>(tab.S, u, v);
+      lds_store<n>(Wc + bx, 1, v);
+    }
+    Sync::sync();
+    // P1: interpolate along y
+    if (act) {
+      lds_load<n>(Wc + by, n, u);
+      mvt<n, 1>(tab.S, u, v);
+      lds_store<n>(Wc + by, n, v);
+    }
+    Sync::sync();
+    // P2: interpolate along z -> values at quadrature points; z-derivative part
+    if (act) {
+      lds_load<n>(Wc + bz, n2, u);
+      lds_load<n>(cf + bz, n2, v);
+      mvt<n, 1>(tab.S, u, w);
+      mv<n, -1>(tab.Dt, w, g);
+#pragma unroll
+      for (int s = 0; s < n; ++s) g[s] *= v[s];
+      mvt<n, -1>(tab.Dt, g, r);
+      lds_store<n>(Wc + bz, n2, w);
+      lds_store<n>(Rc + bz, n2, r);
+    }
+    Sync::sync();
+    // P3: y-derivative part
+    if (act) {
+      lds_load<n>(Wc + by, n, w);
+      lds_load<n>(cf + by, n, v);
+      mv<n, -1>(tab.Dt, w, g);
+#pragma unroll
+      for (int s = 0; s < n; ++s) g[s] *= v[s];
+      mvt<n, -1>(tab.Dt, g, r);
+      lds_load<n>(Rc + by, n, v);
+#pragma unroll
+      for (int s = 0; s < n; ++s) r[s] += v[s];
+      lds_store<n>(Rc + by, n, r);
+    }
+    Sync::sync();
+    // P4: x-derivative part, then S^T along x
+    if (act) {
+      lds_load<n>(Wc + bx, 1, w);
+      lds_load<n>(cf + bx, 1, v);
+      mv<n, -1>(tab.Dt, w, g);
+#pragma unroll
+      for (int s = 0; s < n; ++s) g[s] *= v[s];
+      mvt<n, -1>(tab.Dt, g, r);
+      lds_load<n>(Rc + bx, 1, v);
+#pragma unroll
+      for (int s = 0; s < n; ++s) r[s] += v[s];
+      mv<n, 1>(tab.S, r, v);
+      lds_store<n>(Rc + bx, 1, v);
+    }
+    Sync::sync();
+    // P5: S^T along y; coefficient / index buffers are free now (last read in P4 / at the chunk
+    // start): stage the next chunk
+    if (act) {
+      lds_load<n>(Rc + by, n, u);
+      mv<n, 1>(tab.S, u, v);
+      lds_store<n>(Rc + by, n, v);
+    }
+    stage_next();
+    Sync::sync();
+    // P6: S^T along z, scatter-add into the batch accumulator
+    if (act) {
+      lds_load<n>(Rc + bz, n2, u);
+      mv<n, 1>(tab.S, u, v);
+    }
+    if (HN && any_mask) {
+      // resolve_hanging_nodes_shmem<TRANSPOSE>; the three passes commute, z is applied first
+      // because v is already a z-pencil (reference order x,y,z: hanging_nodes.cuh:767-777)
+      bool type;
+      if (act) {
+        if (mask && hn_flag3<n, 2>(mask, pa, pb, type)) hn_pencil<n, T, true>(Wl, type, v);
+        lds_store<n>(Rc + bz, n2, v);
+      }
+      Sync::sync();
+      if (act) {
+        lds_load<n>(Rc + by, n, v);
+        if (mask && hn_flag3<n, 1>(mask, pb, pa, type)) hn_pencil<n, T, true>(Wl, type, v);
+        lds_store<n>(Rc + by, n, v);
+      }
+      Sync::sync();
+      if (act) {
+        lds_load<n>(Rc + bx, 1, v);
+        if (mask && hn_flag3<n, 0>(mask, pa, pb, type)) hn_pencil<n, T, true>(Wl, type, v);
+#pragma unroll
+        for (int i = 0; i < n; ++i) lds_add(&acc[ix[i]], v[i]);
+      }
+    } else if (act) {
+#pragma unroll
+      for (int k = 0; k < n; ++k) if (!PDBG(16)) lds_add(&acc[iz[k]], v[k]); else asm volatile("" ::"v"(v[k]), "v"(iz[k]));
+    }
+  } else {  // dim == 2
+    if (HN && any_mask) {
+      bool type;
+      if (act) {
+        if (mask && hn_flag2<n, 0>(mask, pa, type)) hn_pencil<n, T, false>(Wl, type, u);
+        lds_store<n>(Wc + bx, 1, u);
+      }
+      Sync::sync();
+      if (act) {
+        lds_load<n>(Wc + by, n, u);
+        if (mask && hn_flag2<n, 1>(mask, pa, type)) hn_pencil<n, T, false>(Wl, type, u);
+        lds_store<n>(Wc + by, n, u);
+      }
+      Sync::sync();
+      if (act) lds_load<n>(Wc + bx, 1, u);
+    }
+    // P0: interpolate along x
+    if (act) {
+      mvt<n, 1>(tab.S, u, v);
+      lds_store<n>(Wc + bx, 1, v);
+    }
+    Sync::sync();
+    // P1: interpolate along y; y-derivative part
+    if (act) {
+      lds_load<n>(Wc + by, n, u);
+      lds_load<n>(cf + by, n, v);
+      mvt<n, 1>(tab.S, u, w);
+      mv<n, -1>(tab.Dt, w, g);
+#pragma unroll
+      for (int s = 0; s < n; ++s) g[s] *= v[s];
+      mvt<n, -1>(tab.Dt, g, r);
+      lds_store<n>(Wc + by, n, w);
+      lds_store<n>(Rc + by, n, r);
+    }
+    Sync::sync();
+    // P2: x-derivative part, S^T along x
+    if (act) {
+      lds_load<n>(Wc + bx, 1, w);
+      lds_load<n>(cf + bx, 1, v);
+      mv<n, -1>(tab.Dt, w, g);
+#pragma unroll
+      for (int s = 0; s < n; ++s) g[s] *= v[s];
+      mvt<n, -1>(tab.Dt, g, r);
+      lds_load<n>(Rc + bx, 1, v);
+#pragma unroll
+      for (int s = 0; s < n; ++s) r[s] += v[s];
+      mv<n, 1>(tab.S, r, v);
+      lds_store<n>(Rc + bx, 1, v);
+    }
+    Sync::sync();
+    // P3: S^T along y, scatter-add
+    if (act) {
+      lds_load<n>(Rc + by, n, u);
+      mv<n, 1>(tab.S, u, v);
+    }
+    if (HN && any_mask) {
+      bool type;
+      if (act) {
+        if (mask && hn_flag2<n, 1>(mask, pa, type)) hn_pencil<n, T, true>(Wl, type, v);
+        lds_store<n>(Rc + by, n, v);
+      }
+      Sync::sync();
+      if (act) {
+        lds_load<n>(Rc + bx, 1, v);
+        if (mask && hn_flag2<n, 0>(mask, pa, type)) hn_pencil<n, T, true>(Wl, type, v);
+#pragma unroll
+        for (int i = 0; i < n; ++i) lds_add(&acc[ix[i]], v[i]);
+      }
+    } else if (act) {
+#pragma unroll
+      for (int k = 0; k < n; ++k) if (!PDBG(16)) lds_add(&acc[iz[k]], v[k]); else asm volatile("" ::"v"(v[k]), "v"(iz[k]));
+    }
+    if (stage_next()) Sync::sync();  // Cb last read in P2, Lb at the chunk start
+  }
+}
+
+// WAVE = false: workgroup = 256 threads = 4 waves; they process CH = 256/P cells at a time and
+//               synchronise the transposes with s_barrier (250 of 256 lanes busy for p=4).
+// WAVE = true : workgroup = ONE wave with its own (smaller) batch: CH = 64/P cells at a time (2 for p=4,
+//               50 of 64 lanes busy); the transposes need only program order inside the wave and no wave
+//               ever waits for another one, so the waves of a CU sit in different phases (gather /
+//               cells / scatter) and memory latency overlaps with LDS and VALU work.
+template <int dim, int n, typename T, bool HN, bool TWOPASS, bool WAVE>
+__global__ void __launch_bounds__(WAVE ? 64 : 256)
 apply_batches(const ApplyArgs<T> A, const Tables<T, n> tab) {
-  constexpr int kGU = (kMaxBatchDofs + kBlock - 1) / kBlock;  // all gather loads of a batch in flight
+  constexpr int kBlock = WAVE ? 64 : 256;
+  constexpr int kGU = (max_batch_dofs(kBlock) + kBlock - 1) / kBlock;  // all gather loads of a batch in flight
   constexpr int nd = (dim == 3) ? n * n * n : n * n;
   constexpr int P = nd / n;          // pencils per cell
-  constexpr int CH = kBlock / P;     // cells per chunk
+  constexpr int NG = 1;                        // independent thread groups per workgroup
+  constexpr int GT = kBlock / NG;              // threads per group
+  constexpr int CH = GT / P;         // cells a group holds at once
   constexpr int n2 = n * n;
   constexpr int CHND = CH * nd;
+  static_assert(CH >= 1, "a cell's pencils must fit into one thread group");
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
   T *usrc = reinterpret_cast<T *>(smem_raw);
   T *acc = usrc + A.nb_max;
-  T *Wb = acc + A.nb_max;
-  T *Rb = Wb + CHND;
-  T *Cb = Rb + CHND;     // folded coefficient of the current chunk
-  T *Wl = Cb + CHND;     // hanging-node weights (HN only), broadcast reads
-  uint16_t *Lb = reinterpret_cast<uint16_t *>(Wl + n2);  // local->batch dof map of the current chunk
-
   const int tid = threadIdx.x;
+  const int grp = 0;
+  const int gtid = tid;
+  T *Wb = acc + A.nb_max + grp * 3 * CHND;
+  T *Rb = Wb + CHND;
+  T *Cb = Rb + CHND;     // folded coefficient of the cells in flight
+  T *Wl = acc + A.nb_max + NG * 3 * CHND;  // hanging-node weights (HN only), broadcast reads
+  uint16_t *Lb = reinterpret_cast<uint16_t *>(Wl + n2) + grp * CHND;  // local->batch dof map of the cells in flight
+
   // Workgroup loops over batches b, b + gridDim.x, ... of [batch0, batch_end) (grid = resident
-  // workgroups).  Cross-batch register prefetch of the dof list / source values was tried and dropped:
-  // hipcc waits vmcnt(0) at the loop back-edge, so it bought nothing and cost 60 VGPRs (occupancy).
+  // workgroups).
   const uint32_t bend = A.batch_end;
   uint32_t b = A.batch0 + blockIdx.x;
   if (b >= bend) return;
+  // Stagger: all workgroups run batches of (nearly) identical length, so workgroups that start together
+  // stay phase-aligned (the whole CU gathers, then the whole CU computes) and the memory and compute
+  // phases never overlap.  Blocks are dealt round-robin over XCDs and CUs, so block b and b + 256 share a
+  // CU (speed only, never correctness): delay the k-th resident workgroup of a CU by k * stagger.
+  if (A.stagger > 0) {
+    const int slot = (int)(blockIdx.x / 256u);
+    for (int k = 0; k < slot * A.stagger; ++k) __builtin_amdgcn_s_sleep(127);  // 127 * 64 cycles each
+  }
   uint32_t c0, d0, hoff;
   int nb, ncell, nint;
   auto load_meta = [&](uint32_t bb, uint32_t &c0_, int &ncell_, uint32_t &d0_, int &nb_, int &nint_,
@@ -193,22 +454,17 @@ apply_batches(const ApplyArgs<T> A, const Tables<T, n> tab) {
     for (int j = 0; j < kGU; ++j) sv_[j] = DBG(2) ? T(0) : A.src[g_[j] & 0x7fffffffu];
   };
 
-  const int lc = tid / P;
-  const int pen = tid - lc * P;
+  const int lc = gtid / P;
+  const int pen = gtid - lc * P;
   const int pa = (dim == 3) ? pen % n : pen;
   const int pb = (dim == 3) ? pen / n : 0;
-  const int bx = (dim == 3) ? n * pa + n2 * pb : n * pa;  // x-pencil, stride 1
-  const int by = (dim == 3) ? pa + n2 * pb : pa;          // y-pencil, stride n
-  const int bz = pa + n * pb;                             // z-pencil, stride n2 (3D only)
-  constexpr int sl = (dim == 3) ? n2 : n;                 // stride of the last direction
-  const int bl = (dim == 3) ? bz : by;                    // pencil base of the last direction
 
   // Per-chunk streams (folded coefficient, local->batch index map) are contiguous in plan order.  They
   // are fetched ONE CHUNK AHEAD with fully coalesced loads into registers and staged in LDS, from where
   // every pencil layout reads them.  Loading them per layout straight from global memory touched up to
   // 64 distinct cache lines per wave instruction (x-layout: 40-byte lane stride) and made the CU's L1
   // line-access rate the bottleneck (profiles/, round 1).
-  constexpr int PF = (CHND + kBlock - 1) / kBlock;
+  constexpr int PF = (CHND + GT - 1) / GT;
   T pc[PF];
   uint16_t pl[PF];
   auto prefetch = [&](uint32_t cell0, int cnt) {
@@ -216,7 +472,7 @@ apply_batches(const ApplyArgs<T> A, const Tables<T, n> tab) {
     const uint16_t *lg = A.lmap + (size_t)cell0 * nd;
 #pragma unroll
     for (int j = 0; j < PF; ++j) {
-      const int i = tid + j * kBlock;
+      const int i = gtid + j * GT;
       const int ic = i < cnt ? i : cnt - 1;  // clamped, branch-free
       pc[j] = cg[ic];
       pl[j] = lg[ic];
@@ -225,7 +481,7 @@ apply_batches(const ApplyArgs<T> A, const Tables<T, n> tab) {
   auto stage = [&](int cnt) {
 #pragma unroll
     for (int j = 0; j < PF; ++j) {
-      const int i = tid + j * kBlock;
+      const int i = gtid + j * GT;
       if (i < cnt) {
         Cb[i] = pc[j];
         Lb[i] = pl[j];
@@ -237,19 +493,28 @@ apply_batches(const ApplyArgs<T> A, const Tables<T, n> tab) {
   }
   T *Wc = Wb + lc * nd;
   T *Rc = Rb + lc * nd;
-  while (true) {
-  STAMP(0);
+  auto chunk_count = [&](int ncell_, int base_) { return (ncell_ - base_ < CH ? ncell_ - base_ : CH) * nd; };
+
+  // ---- software pipeline over batches: while batch b is computed, ALL global loads of the workgroup's
+  // next batch are in flight (its dof list from the start, its source values after the first chunk,
+  // its first coefficient / index chunk during b's last chunk).  A workgroup that gathers, computes and
+  // scatters strictly in turn keeps HBM idle while it computes: memory (80 us alone) and cell (110 us
+  // alone) phases ADDED UP in that version (profiles/r01_notes.md).
+  // No global load is issued between the loop top and the first use of the prefetched registers: hipcc
+  // waits vmcnt(0) after the loop back-edge, which must find only completed loads.
+  uint32_t G[kGU];
+  uint8_t F[kGU];
+  T SV[kGU];
   load_meta(b, c0, ncell, d0, nb, nint, hoff);
-  const int cnt0 = (ncell < CH ? ncell : CH) * nd;
-  if (!DBG(8)) prefetch(c0, cnt0);  // in flight during the gather
-  // ---- 1. gather (read_dof_values, fee_gpu.cuh:323-331, once per batch dof).  bdofs bit 31 = constrained row: reads as 0 (constraint_handler_gpu.cu:258-259) and,
-  // if this batch owns the row, dst = src is written here (identity rows, :286).
-  {
-    uint32_t G[kGU];
-    uint8_t F[kGU];
-    T SV[kGU];
-    load_dofs(d0, nb, G, F);
-    load_src(G, SV);
+  load_dofs(d0, nb, G, F);
+  if (!DBG(8)) prefetch(c0, chunk_count(ncell, 0));
+  load_src(G, SV);
+  stage(chunk_count(ncell, 0));
+  while (true) {
+    STAMP(0);
+    // ---- 1. gather (read_dof_values, fee_gpu.cuh:323-331, once per batch dof): the values are already
+    // in registers.  bdofs bit 31 = constrained row: reads as 0 (constraint_handler_gpu.cu:258-259) and,
+    // if this batch owns the row, dst = src is written here (identity rows, :286).
 #pragma unroll
     for (int j = 0; j < kGU; ++j) {
       const int t = tid + j * kBlock;
@@ -264,285 +529,115 @@ apply_batches(const ApplyArgs<T> A, const Tables<T, n> tab) {
         }
       }
     }
-  }
-  const uint32_t bn = b + gridDim.x;
-  const bool has_nb = bn < bend;
-  STAMP(2);
-  stage(cnt0);
-  __syncthreads();
-  STAMP(3);
-
-  // ---- 2. cells
-  const int ncell_eff = DBG(1) ? 0 : ncell;
-  for (int base = 0; base < ncell_eff; base += CH) {
-    const bool act = (tid < CH * P) && (base + lc < ncell);
-    const int nxt = base + CH;
-    const bool has_next = nxt < ncell;
-    const int cnt_next = has_next ? ((ncell - nxt < CH ? ncell - nxt : CH) * nd) : 0;
-    if (has_next && !DBG(8)) prefetch(c0 + nxt, cnt_next);
-    const T *cf = Cb + lc * nd;
-    const uint16_t *lm = Lb + lc * nd;
-    unsigned mask = 0;
-    bool any_mask = false;
-    if (HN) {
-      if (act) mask = A.cmask[(size_t)c0 + base + lc];
-      any_mask = __syncthreads_or(mask != 0);
+    // next batch of this workgroup: meta data and dof list (the iteration's first global loads)
+    const uint32_t bn = b + gridDim.x;
+    const bool has_nb = bn < bend;
+    uint32_t c0n = c0, d0n = d0, hoffn = hoff;
+    int nbn = nb, ncelln = ncell, nintn = nint;
+    uint32_t Gn[kGU];
+    uint8_t Fn[kGU];
+    T SVn[kGU];
+    if (has_nb) {
+      load_meta(bn, c0n, ncelln, d0n, nbn, nintn, hoffn);
+      load_dofs(d0n, nbn, Gn, Fn);
     }
-    T u[n], v[n], w[n], g[n], r[n];
-    uint16_t ix[n], iz[n];
-    if (act) {
-#pragma unroll
-      for (int i = 0; i < n; ++i) {
-        ix[i] = lm[bx + i];
-        iz[i] = lm[bl + i * sl];
-      }
-#pragma unroll
-      for (int i = 0; i < n; ++i) u[i] = usrc[ix[i]];
-    }
+    STAMP(2);
+    __syncthreads();
+    STAMP(3);
 
-    if (dim == 3) {
-      if (HN && any_mask) {
-        // resolve_hanging_nodes_shmem<NOTRANSPOSE>: x, then y, then z (hanging_nodes.cuh:767-777)
-        bool type;
-        if (act) {
-          if (mask && hn_flag3<n, 0>(mask, pa, pb, type)) hn_pencil<n, T, false>(Wl, type, u);
-          lds_store<n>(Wc + bx, 1, u);
-        }
-        __syncthreads();
-        if (act) {
-          lds_load<n>(Wc + by, n, u);
-          if (mask && hn_flag3<n, 1>(mask, pb, pa, type)) hn_pencil<n, T, false>(Wl, type, u);
-          lds_store<n>(Wc + by, n, u);
-        }
-        __syncthreads();
-        if (act) {
-          lds_load<n>(Wc + bz, n2, u);
-          if (mask && hn_flag3<n, 2>(mask, pa, pb, type)) hn_pencil<n, T, false>(Wl, type, u);
-          lds_store<n>(Wc + bz, n2, u);
-        }
-        __syncthreads();
-        if (act) lds_load<n>(Wc + bx, 1, u);  // P0 rewrites the same pencil in place
+    // ---- 2. cells
+    const int ncell_eff = DBG(1) ? 0 : ncell;
+    for (int base = 0; base < ncell_eff; base += CH) {
+      const bool act = (gtid < CH * P) && (base + lc < ncell);
+      const int nxt = base + CH;
+      // coefficient / index stream of the next chunk: of this batch, or the first one of the next batch
+      int cnt_next = 0;
+      if (nxt < ncell) {
+        cnt_next = chunk_count(ncell, nxt);
+        if (!DBG(8)) prefetch(c0 + nxt, cnt_next);
+      } else if (has_nb) {
+        cnt_next = chunk_count(ncelln, 0);
+        if (!DBG(8)) prefetch(c0n, cnt_next);
       }
-      // P0: interpolate along x
-      if (act) {
-        mvt<n, 1>(tab.S, u, v);
-        lds_store<n>(Wc + bx, 1, v);
+      const T *cf = Cb + lc * nd;
+      const uint16_t *lm = Lb + lc * nd;
+      unsigned mask = 0;
+      bool any_mask = false;
+      if (HN) {
+        if (act) mask = A.cmask[(size_t)c0 + base + lc];
+        any_mask = __syncthreads_or(mask != 0) != 0;
       }
-      __syncthreads();
-      // P1: interpolate along y
-      if (act) {
-        lds_load<n>(Wc + by, n, u);
-        mvt<n, 1>(tab.S, u, v);
-        lds_store<n>(Wc + by, n, v);
-      }
-      __syncthreads();
-      // P2: interpolate along z -> values at quadrature points; z-derivative part
-      if (act) {
-        lds_load<n>(Wc + bz, n2, u);
-        lds_load<n>(cf + bz, n2, v);
-        mvt<n, 1>(tab.S, u, w);
-        mv<n, -1>(tab.Dt, w, g);
-#pragma unroll
-        for (int s = 0; s < n; ++s) g[s] *= v[s];
-        mvt<n, -1>(tab.Dt, g, r);
-        lds_store<n>(Wc + bz, n2, w);
-        lds_store<n>(Rc + bz, n2, r);
-      }
-      __syncthreads();
-      // P3: y-derivative part
-      if (act) {
-        lds_load<n>(Wc + by, n, w);
-        lds_load<n>(cf + by, n, v);
-        mv<n, -1>(tab.Dt, w, g);
-#pragma unroll
-        for (int s = 0; s < n; ++s) g[s] *= v[s];
-        mvt<n, -1>(tab.Dt, g, r);
-        lds_load<n>(Rc + by, n, v);
-#pragma unroll
-        for (int s = 0; s < n; ++s) r[s] += v[s];
-        lds_store<n>(Rc + by, n, r);
-      }
-      __syncthreads();
-      // P4: x-derivative part, then S^T along x
-      if (act) {
-        lds_load<n>(Wc + bx, 1, w);
-        lds_load<n>(cf + bx, 1, v);
-        mv<n, -1>(tab.Dt, w, g);
-#pragma unroll
-        for (int s = 0; s < n; ++s) g[s] *= v[s];
-        mvt<n, -1>(tab.Dt, g, r);
-        lds_load<n>(Rc + bx, 1, v);
-#pragma unroll
-        for (int s = 0; s < n; ++s) r[s] += v[s];
-        mv<n, 1>(tab.S, r, v);
-        lds_store<n>(Rc + bx, 1, v);
-      }
-      __syncthreads();
-      // P5: S^T along y; coefficient / index buffers are free now (last read in P4 / at the chunk
-      // start): stage the next chunk
-      if (act) {
-        lds_load<n>(Rc + by, n, u);
-        mv<n, 1>(tab.S, u, v);
-        lds_store<n>(Rc + by, n, v);
-      }
-      if (has_next) stage(cnt_next);
-      __syncthreads();
-      // P6: S^T along z, scatter-add into the batch accumulator
-      if (act) {
-        lds_load<n>(Rc + bz, n2, u);
-        mv<n, 1>(tab.S, u, v);
-      }
-      if (HN && any_mask) {
-        // resolve_hanging_nodes_shmem<TRANSPOSE>; the three passes commute, z is applied first
-        // because v is already a z-pencil (reference order x,y,z: hanging_nodes.cuh:767-777)
-        bool type;
-        if (act) {
-          if (mask && hn_flag3<n, 2>(mask, pa, pb, type)) hn_pencil<n, T, true>(Wl, type, v);
-          lds_store<n>(Rc + bz, n2, v);
-        }
-        __syncthreads();
-        if (act) {
-          lds_load<n>(Rc + by, n, v);
-          if (mask && hn_flag3<n, 1>(mask, pb, pa, type)) hn_pencil<n, T, true>(Wl, type, v);
-          lds_store<n>(Rc + by, n, v);
-        }
-        __syncthreads();
-        if (act) {
-          lds_load<n>(Rc + bx, 1, v);
-          if (mask && hn_flag3<n, 0>(mask, pa, pb, type)) hn_pencil<n, T, true>(Wl, type, v);
-#pragma unroll
-          for (int i = 0; i < n; ++i) lds_add(&acc[ix[i]], v[i]);
-        }
-      } else if (act) {
-#pragma unroll
-        for (int k = 0; k < n; ++k) lds_add(&acc[iz[k]], v[k]);
-      }
-    } else {  // dim == 2
-      if (HN && any_mask) {
-        bool type;
-        if (act) {
-          if (mask && hn_flag2<n, 0>(mask, pa, type)) hn_pencil<n, T, false>(Wl, type, u);
-          lds_store<n>(Wc + bx, 1, u);
-        }
-        __syncthreads();
-        if (act) {
-          lds_load<n>(Wc + by, n, u);
-          if (mask && hn_flag2<n, 1>(mask, pa, type)) hn_pencil<n, T, false>(Wl, type, u);
-          lds_store<n>(Wc + by, n, u);
-        }
-        __syncthreads();
-        if (act) lds_load<n>(Wc + bx, 1, u);
-      }
-      // P0: interpolate along x
-      if (act) {
-        mvt<n, 1>(tab.S, u, v);
-        lds_store<n>(Wc + bx, 1, v);
-      }
-      __syncthreads();
-      // P1: interpolate along y; y-derivative part
-      if (act) {
-        lds_load<n>(Wc + by, n, u);
-        lds_load<n>(cf + by, n, v);
-        mvt<n, 1>(tab.S, u, w);
-        mv<n, -1>(tab.Dt, w, g);
-#pragma unroll
-        for (int s = 0; s < n; ++s) g[s] *= v[s];
-        mvt<n, -1>(tab.Dt, g, r);
-        lds_store<n>(Wc + by, n, w);
-        lds_store<n>(Rc + by, n, r);
-      }
-      __syncthreads();
-      // P2: x-derivative part, S^T along x
-      if (act) {
-        lds_load<n>(Wc + bx, 1, w);
-        lds_load<n>(cf + bx, 1, v);
-        mv<n, -1>(tab.Dt, w, g);
-#pragma unroll
-        for (int s = 0; s < n; ++s) g[s] *= v[s];
-        mvt<n, -1>(tab.Dt, g, r);
-        lds_load<n>(Rc + bx, 1, v);
-#pragma unroll
-        for (int s = 0; s < n; ++s) r[s] += v[s];
-        mv<n, 1>(tab.S, r, v);
-        lds_store<n>(Rc + bx, 1, v);
-      }
-      __syncthreads();
-      // P3: S^T along y, scatter-add
-      if (act) {
-        lds_load<n>(Rc + by, n, u);
-        mv<n, 1>(tab.S, u, v);
-      }
-      if (HN && any_mask) {
-        bool type;
-        if (act) {
-          if (mask && hn_flag2<n, 1>(mask, pa, type)) hn_pencil<n, T, true>(Wl, type, v);
-          lds_store<n>(Rc + by, n, v);
-        }
-        __syncthreads();
-        if (act) {
-          lds_load<n>(Rc + bx, 1, v);
-          if (mask && hn_flag2<n, 0>(mask, pa, type)) hn_pencil<n, T, true>(Wl, type, v);
-#pragma unroll
-          for (int i = 0; i < n; ++i) lds_add(&acc[ix[i]], v[i]);
-        }
-      } else if (act) {
-#pragma unroll
-        for (int k = 0; k < n; ++k) lds_add(&acc[iz[k]], v[k]);
-      }
-      if (has_next) {
-        stage(cnt_next);  // Cb last read in P2, Lb at the chunk start
-        __syncthreads();
-      }
+      auto stage_next = [&]() {
+        if (cnt_next > 0) stage(cnt_next);
+        return cnt_next > 0;
+      };
+      if (WAVE)
+        cell_pipeline<dim, n, T, HN, WaveSync>(act, pa, pb, mask, any_mask, usrc, acc, Wc, Rc, cf, lm, Wl, tab, stage_next, A.dbg);
+      else
+        cell_pipeline<dim, n, T, HN, WgSync>(act, pa, pb, mask, any_mask, usrc, acc, Wc, Rc, cf, lm, Wl, tab, stage_next, A.dbg);
+      // Wc is next written in P0 of the following chunk and was last read in P4 (P2 in 2D); Rc is next
+      // written in P2 (P1) and was last read before the scatter-add: both separated by barriers.
+      if (base == 0 && has_nb) load_src(Gn, SVn);  // the next batch's dof list has landed by now
+      STAMP(4 + (base / CH < 8 ? base / CH : 8));
     }
-    // Wc is next written in P0 of the following chunk and was last read in P4 (P2 in 2D); Rc is next
-    // written in P2 (P1) and was last read before the scatter-add: both separated by barriers.
-    STAMP(4 + (base / CH < 8 ? base / CH : 8));
-  }
-  __syncthreads();
-  STAMP(13);
+    if (ncell_eff == 0 && has_nb) {  // diagnostic builds only (cells skipped)
+      prefetch(c0n, chunk_count(ncelln, 0));
+      load_src(Gn, SVn);
+      stage(chunk_count(ncelln, 0));
+    }
+    __syncthreads();
+    STAMP(13);
 
-  // ---- 4. scatter (distribute_local_to_global fee_gpu.cuh:346-363 + identity rows
-  //         constraint_handler_gpu.cu:276-289), one write per batch dof.  The dof list is re-read
-  //         (L2 hit) rather than kept in 9 VGPRs across the cell loop.
-  uint32_t G[kGU];
-  uint8_t F[kGU];
-  load_dofs(d0, nb, G, F);
-  if (TWOPASS) {
-    // batch dofs are ordered [interior | shared]: interior dofs belong to this batch alone and are
-    // final; partial sums of shared dofs go to the batch's contiguous halo slots (reduce_shared)
-    T *halo = A.halo + hoff;
-    if (!DBG(4)) {
+    // ---- 3. scatter (distribute_local_to_global fee_gpu.cuh:346-363 + identity rows
+    //         constraint_handler_gpu.cu:276-289), one write per batch dof
+    if (TWOPASS) {
+      // batch dofs are ordered [interior | shared]: interior dofs belong to this batch alone and are
+      // final; partial sums of shared dofs go to the batch's contiguous halo slots (reduce_shared)
+      T *halo = A.halo + hoff;
+      if (!DBG(4)) {
+        T old[kGU];
+        if (A.add) {  // uniform branch
+#pragma unroll
+          for (int j = 0; j < kGU; ++j) old[j] = A.dst[G[j] & 0x7fffffffu];
+        }
+#pragma unroll
+        for (int j = 0; j < kGU; ++j) {
+          const int t = tid + j * kBlock;
+          if (t < nint) {
+            if (!(G[j] >> 31)) A.dst[G[j]] = A.add ? old[j] + acc[t] : acc[t];
+          } else if (t < nb) {
+            halo[t - nint] = acc[t];  // constrained shared dofs: value ignored by reduce_shared
+          }
+        }
+      }
+    } else if (!DBG(4)) {
+      // later colours (and vmult_add) read-modify-write; the read is unconditional to keep the loads
+      // free of per-element branches
       T old[kGU];
-      if (A.add) {  // uniform branch
 #pragma unroll
-        for (int j = 0; j < kGU; ++j) old[j] = A.dst[G[j] & 0x7fffffffu];
-      }
+      for (int j = 0; j < kGU; ++j) old[j] = A.dst[G[j] & 0x7fffffffu];
 #pragma unroll
       for (int j = 0; j < kGU; ++j) {
         const int t = tid + j * kBlock;
-        if (t < nint) {
-          if (!(G[j] >> 31)) A.dst[G[j]] = A.add ? old[j] + acc[t] : acc[t];
-        } else if (t < nb) {
-          halo[t - nint] = acc[t];  // constrained shared dofs: value ignored by reduce_shared
-        }
+        if (t < nb && !(G[j] >> 31)) A.dst[G[j]] = ((F[j] & kFlagAdd) || A.add) ? old[j] + acc[t] : acc[t];
       }
     }
-  } else if (!DBG(4)) {
-    // later colours (and vmult_add) read-modify-write; the read is unconditional to keep the loads
-    // free of per-element branches
-    T old[kGU];
-#pragma unroll
-    for (int j = 0; j < kGU; ++j) old[j] = A.dst[G[j] & 0x7fffffffu];
+    STAMP(15);
+    if (!has_nb) break;
+    __syncthreads();  // usrc / acc are rewritten for the next batch
+    b = bn;
+    c0 = c0n;
+    ncell = ncelln;
+    d0 = d0n;
+    nb = nbn;
+    nint = nintn;
+    hoff = hoffn;
 #pragma unroll
     for (int j = 0; j < kGU; ++j) {
-      const int t = tid + j * kBlock;
-      if (t < nb && !(G[j] >> 31)) A.dst[G[j]] = ((F[j] & kFlagAdd) || A.add) ? old[j] + acc[t] : acc[t];
+      G[j] = Gn[j];
+      F[j] = Fn[j];
+      SV[j] = SVn[j];
     }
-  }
-  STAMP(15);
-  if (!has_nb) break;
-  __syncthreads();  // usrc / acc are rewritten for the next batch
-  b = bn;
   }  // batch loop
 }
 
@@ -621,48 +716,49 @@ __global__ void fill_kernel(T *v, size_t n, T a) {
 // ---------------------------------------------------------------------------------------------
 
 template <int dim, int n, typename T>
-static size_t lds_bytes_t(uint32_t nb_max, int kBlock) {
+static size_t lds_bytes_t(uint32_t nb_max, bool wave) {
   constexpr int nd = (dim == 3) ? n * n * n : n * n;
-  const int CH = kBlock / (nd / n);
-  return (size_t)(2 * nb_max + 3 * CH * nd + n * n) * sizeof(T) + (size_t)CH * nd * sizeof(uint16_t);
+  const int NG = 1;
+  const int CH = (wave ? 64 : 256) / (nd / n);
+  return (size_t)(2 * nb_max + NG * 3 * CH * nd + n * n) * sizeof(T) + (size_t)NG * CH * nd * sizeof(uint16_t);
 }
 
-template <int dim, int n, typename T, bool HN, bool TP, int KB>
+template <int dim, int n, typename T, bool HN, bool TP, bool WV>
 static hipError_t launch_k(const ApplyArgs<T> &a, const Tables<T, n> &tab, size_t lds, uint32_t grid, hipStream_t st) {
-  hipLaunchKernelGGL((apply_batches<dim, n, T, HN, TP, KB>), dim3(grid), dim3(KB), lds, st, a, tab);
+  hipLaunchKernelGGL((apply_batches<dim, n, T, HN, TP, WV>), dim3(grid), dim3(WV ? 64 : 256), lds, st, a, tab);
   return hipGetLastError();
 }
 
 // dispatch over the run-time switches (hanging nodes, scatter mode, workgroup size)
 #define MFGPU_SWITCH(FN, ...)                                                       \
-  (kb == 512 ? (hn ? (twopass ? FN<dim, n, T, true, true, 512>(__VA_ARGS__)          \
-                              : FN<dim, n, T, true, false, 512>(__VA_ARGS__))        \
-                   : (twopass ? FN<dim, n, T, false, true, 512>(__VA_ARGS__)         \
-                              : FN<dim, n, T, false, false, 512>(__VA_ARGS__)))      \
-             : (hn ? (twopass ? FN<dim, n, T, true, true, 256>(__VA_ARGS__)          \
-                              : FN<dim, n, T, true, false, 256>(__VA_ARGS__))        \
-                   : (twopass ? FN<dim, n, T, false, true, 256>(__VA_ARGS__)         \
-                              : FN<dim, n, T, false, false, 256>(__VA_ARGS__))))
+  (wave ? (hn ? (twopass ? FN<dim, n, T, true, true, true>(__VA_ARGS__)              \
+                         : FN<dim, n, T, true, false, true>(__VA_ARGS__))            \
+              : (twopass ? FN<dim, n, T, false, true, true>(__VA_ARGS__)             \
+                         : FN<dim, n, T, false, false, true>(__VA_ARGS__)))          \
+        : (hn ? (twopass ? FN<dim, n, T, true, true, false>(__VA_ARGS__)             \
+                         : FN<dim, n, T, true, false, false>(__VA_ARGS__))           \
+              : (twopass ? FN<dim, n, T, false, true, false>(__VA_ARGS__)            \
+                         : FN<dim, n, T, false, false, false>(__VA_ARGS__))))
 
 template <int dim, int n, typename T>
 static hipError_t launch_t(const ApplyArgs<T> &a, const double *S, const double *Dt, bool hn,
-                           bool twopass, int kb, uint32_t grid, hipStream_t st) {
+                           bool twopass, bool wave, uint32_t grid, hipStream_t st) {
   Tables<T, n> tab;
   for (int i = 0; i < ((n + 1) / 2) * n; ++i) {
     tab.S[i] = (T)S[i];
     tab.Dt[i] = (T)Dt[i];
   }
-  const size_t lds = lds_bytes_t<dim, n, T>(a.nb_max, kb);
+  const size_t lds = lds_bytes_t<dim, n, T>(a.nb_max, wave);
   return MFGPU_SWITCH(launch_k, a, tab, lds, grid, st);
 }
 
-template <int dim, int n, typename T, bool HN, bool TP, int KB>
+template <int dim, int n, typename T, bool HN, bool TP, bool WV>
 static hipError_t configure_k(size_t lds) {
-  return hipFuncSetAttribute((const void *)apply_batches<dim, n, T, HN, TP, KB>,
+  return hipFuncSetAttribute((const void *)apply_batches<dim, n, T, HN, TP, WV>,
                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
 }
 template <int dim, int n, typename T>
-static hipError_t configure_t(size_t lds, int kb) {
+static hipError_t configure_t(size_t lds, bool wave) {
   hipError_t e = hipSuccess;
   for (int hn_ = 0; hn_ < 2 && e == hipSuccess; ++hn_)
     for (int tp_ = 0; tp_ < 2 && e == hipSuccess; ++tp_) {
@@ -672,12 +768,12 @@ static hipError_t configure_t(size_t lds, int kb) {
   return e;
 }
 
-template <int dim, int n, typename T, bool HN, bool TP, int KB>
+template <int dim, int n, typename T, bool HN, bool TP, bool WV>
 static hipError_t occupancy_k(size_t lds, int *blocks) {
-  return hipOccupancyMaxActiveBlocksPerMultiprocessor(blocks, apply_batches<dim, n, T, HN, TP, KB>, KB, lds);
+  return hipOccupancyMaxActiveBlocksPerMultiprocessor(blocks, apply_batches<dim, n, T, HN, TP, WV>, WV ? 64 : 256, lds);
 }
 template <int dim, int n, typename T>
-static hipError_t occupancy_t(bool hn, bool twopass, int kb, size_t lds, int *blocks) {
+static hipError_t occupancy_t(bool hn, bool twopass, bool wave, size_t lds, int *blocks) {
   return MFGPU_SWITCH(occupancy_k, lds, blocks);
 }
 
@@ -699,8 +795,8 @@ static hipError_t occupancy_t(bool hn, bool twopass, int kb, size_t lds, int *bl
   }
 
 template <typename T>
-size_t apply_lds_bytes(int dim, int n, uint32_t nb_max, int kb) {
-#define CALL(D, N) lds_bytes_t<D, N, T>(nb_max, kb)
+size_t apply_lds_bytes(int dim, int n, uint32_t nb_max, bool wave) {
+#define CALL(D, N) lds_bytes_t<D, N, T>(nb_max, wave)
   switch (dim * 10 + n) {
     case 22: return CALL(2, 2);
     case 23: return CALL(2, 3);
@@ -720,23 +816,23 @@ size_t apply_lds_bytes(int dim, int n, uint32_t nb_max, int kb) {
 }
 
 template <typename T>
-hipError_t apply_configure(int dim, int n, size_t lds, int kb) {
-#define CALL(D, N) configure_t<D, N, T>(lds, kb)
+hipError_t apply_configure(int dim, int n, size_t lds, bool wave) {
+#define CALL(D, N) configure_t<D, N, T>(lds, wave)
   MFGPU_DISPATCH(CALL)
 #undef CALL
 }
 
 template <typename T>
-hipError_t apply_occupancy(int dim, int n, bool hn, bool twopass, int kb, size_t lds, int *blocks) {
-#define CALL(D, N) occupancy_t<D, N, T>(hn, twopass, kb, lds, blocks)
+hipError_t apply_occupancy(int dim, int n, bool hn, bool twopass, bool wave, size_t lds, int *blocks) {
+#define CALL(D, N) occupancy_t<D, N, T>(hn, twopass, wave, lds, blocks)
   MFGPU_DISPATCH(CALL)
 #undef CALL
 }
 
 template <typename T>
 hipError_t apply_launch(int dim, int n, const ApplyArgs<T> &a, const double *S, const double *Dt,
-                        bool hn, bool twopass, int kb, uint32_t grid, hipStream_t st) {
-#define CALL(D, N) launch_t<D, N, T>(a, S, Dt, hn, twopass, kb, grid, st)
+                        bool hn, bool twopass, bool wave, uint32_t grid, hipStream_t st) {
+#define CALL(D, N) launch_t<D, N, T>(a, S, Dt, hn, twopass, wave, grid, st)
   MFGPU_DISPATCH(CALL)
 #undef CALL
 }
@@ -787,11 +883,11 @@ hipError_t fill_launch(T *v, size_t n, T a, hipStream_t st) {
 }
 
 #define INST(T)                                                                                         \
-  template size_t apply_lds_bytes<T>(int, int, uint32_t, int);                                          \
-  template hipError_t apply_configure<T>(int, int, size_t, int);                                        \
-  template hipError_t apply_occupancy<T>(int, int, bool, bool, int, size_t, int *);                     \
+  template size_t apply_lds_bytes<T>(int, int, uint32_t, bool);                                         \
+  template hipError_t apply_configure<T>(int, int, size_t, bool);                                       \
+  template hipError_t apply_occupancy<T>(int, int, bool, bool, bool, size_t, int *);                    \
   template hipError_t apply_launch<T>(int, int, const ApplyArgs<T> &, const double *, const double *,   \
-                                      bool, bool, int, uint32_t, hipStream_t);                          \
+                                      bool, bool, bool, uint32_t, hipStream_t);                         \
   template hipError_t reduce_launch<T>(T *, const T *, const T *, const uint32_t *, const uint32_t *,   \
                                        const uint32_t *, uint32_t, int, hipStream_t);                   \
   template hipError_t orphan_launch<T>(T *, const T *, const uint32_t *, uint32_t, int, hipStream_t);   \

@@ -4,8 +4,12 @@ contributions summed over RCCL (torch.distributed backend "nccl") after each vmu
 The reference is single-GPU (no MPI/NCCL anywhere); this is new work mapped to
 xGMI's point-to-point topology: a slab shares dofs only with its two z-neighbours,
 so the exchange is one 2-rank all-reduce per interface plane ((p*n+1)^2 dofs) over the direct
-xGMI link, not an 8-rank collective.  `mode="allreduce"` keeps the literal dense all-reduce over all
-interface planes as the simple validated fallback.
+xGMI link, not an 8-rank collective.  Modes:
+  "p2p"       (default) both neighbours in ONE grouped RCCL send/recv (batch_isend_irecv); the interface
+              planes of a z-slab are contiguous slices of the lexicographic dof vector, so nothing is
+              packed: send the slice, add the received plane (masked on constrained rows)
+  "pair"      one 2-rank all-reduce per interface plane, even interfaces then odd ones
+  "allreduce" the literal dense all-reduce over all interface planes (simple validated fallback)
 
 Everything here works on CPU tensors with the gloo backend as well (tests/test_distributed.py).
 """
@@ -33,7 +37,7 @@ class SlabExchange:
     values are consistent without a second exchange.  Constrained (Dirichlet) interface dofs are
     identity rows on both sides and are not summed."""
 
-    def __init__(self, mesh, rank: int, world: int, device, dtype, mode: str = "pair"):
+    def __init__(self, mesh, rank: int, world: int, device, dtype, mode: str = "p2p"):
         import torch
         import torch.distributed as dist
 
@@ -50,6 +54,14 @@ class SlabExchange:
             self.free[which] = torch.as_tensor((~np.isin(ids, con)).astype(np.float64), device=device).to(dtype)
             self.peer[which] = peer
         self.plane = next(iter(self.idx.values())).numel() if self.idx else 0
+        # contiguous fast path: lower plane = first `plane` entries, upper plane = last ones
+        n_dofs = mesh.n_dofs
+        self.slices = {}
+        for which, ids in self.idx.items():
+            lo = int(ids[0].item())
+            if bool((ids == torch.arange(lo, lo + self.plane, device=ids.device)).all()):
+                self.slices[which] = slice(lo, lo + self.plane)
+        self.recv = {w: torch.empty(self.plane, device=device, dtype=dtype) for w in self.idx}
         self.pair_groups = {}
         if world > 1 and mode == "pair":
             # every rank must create every group, in the same order
@@ -67,7 +79,21 @@ class SlabExchange:
         if self.world == 1 or not self.idx:
             return
         torch, dist = self.torch, self.dist
-        if self.mode == "pair":
+        if self.mode == "p2p":
+            ops, views = [], {}
+            for which in self.idx:
+                v = dst[self.slices[which]] if which in self.slices else dst[self.idx[which]]
+                views[which] = v
+                ops.append(dist.P2POp(dist.isend, v, self.peer[which]))
+                ops.append(dist.P2POp(dist.irecv, self.recv[which], self.peer[which]))
+            for r in dist.batch_isend_irecv(ops):
+                r.wait()
+            for which in self.idx:
+                if which in self.slices:
+                    views[which].addcmul_(self.recv[which], self.free[which])
+                else:
+                    dst[self.idx[which]] = views[which] + self.recv[which] * self.free[which]
+        elif self.mode == "pair":
             # even interfaces (0-1, 2-3, ...) first, then odd ones: every rank is in at most one
             # collective per phase, so the two phases cannot deadlock
             for phase in (0, 1):
@@ -101,7 +127,7 @@ class DistributedLaplace:
     `local_vmult(dst, src)` is injectable so the CPU tests can drive the same exchange code with the
     oracle as the local operator."""
 
-    def __init__(self, mesh, rank, world, device, dtype, local_vmult, mode="pair"):
+    def __init__(self, mesh, rank, world, device, dtype, local_vmult, mode="p2p"):
         self.local_vmult = local_vmult
         self.exchange = SlabExchange(mesh, rank, world, device, dtype, mode)
 

@@ -45,7 +45,7 @@ def _worker(rank, world, port, mode, dim, p, n, q):
     dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("world,mode", [(2, "pair"), (3, "pair"), (2, "allreduce")])
+@pytest.mark.parametrize("world,mode", [(2, "p2p"), (3, "p2p"), (2, "pair"), (3, "pair"), (2, "allreduce")])
 def test_slab_partition_matches_single_domain(world, mode):
     import torch.multiprocessing as mp
 

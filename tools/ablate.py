@@ -28,7 +28,7 @@ if len(sys.argv) > 1 and sys.argv[1] == "child":
     print(f"dbg={os.environ.get('MFGPU_DBG','0'):>2s} bc={bc:2d}: {1e6*(time.perf_counter()-t0)/K:8.1f} us/vmult  (host enqueue {1e6*(t1-t0)/K:8.1f} us/vmult)")
 else:
     n = int(sys.argv[1]) if len(sys.argv) > 1 else 54
-    for bc in (27,):
-        for dbg in (0, 1, 6, 8, 14, 7, 15):
+    for bc in (int(os.environ.get("ABL_BC", "27")),):
+        for dbg in (0, 16, 32, 48, 14, 14+16, 14+48):
             env = dict(os.environ, MFGPU_DBG=str(dbg))
             subprocess.run([sys.executable, __file__, "child", str(n), str(bc)], env=env)
