@@ -389,8 +389,13 @@ __device__ __forceinline__ void cell_pipeline(const bool act, const int pa, cons
 //               50 of 64 lanes busy); the transposes need only program order inside the wave and no wave
 //               ever waits for another one, so the waves of a CU sit in different phases (gather /
 //               cells / scatter) and memory latency overlaps with LDS and VALU work.
+// The hanging-node variant needs 258 VGPRs uncapped, one more allocation granule than two waves per
+// SIMD allow; LDS already limits the kernel to two workgroups per CU, so cap it there.
+template <int n>
+constexpr int min_waves_per_simd() { return n <= 5 ? 2 : 1; }
+
 template <int dim, int n, typename T, bool HN, bool TWOPASS, bool WAVE>
-__global__ void __launch_bounds__(WAVE ? 64 : 256)
+__global__ void __launch_bounds__(WAVE ? 64 : 256) __attribute__((amdgpu_waves_per_eu(min_waves_per_simd<n>())))
 apply_batches(const ApplyArgs<T> A, const Tables<T, n> tab) {
   constexpr int kBlock = WAVE ? 64 : 256;
   constexpr int kGU = (max_batch_dofs(kBlock) + kBlock - 1) / kBlock;  // all gather loads of a batch in flight

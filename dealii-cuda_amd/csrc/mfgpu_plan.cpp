@@ -195,6 +195,11 @@ int build_plan(const mfgpu_desc &d, Plan &P) {
     }
   }
   const uint32_t nb = (uint32_t)batches.size();
+  // cells with a hanging-node mask first: the kernel takes the extra interpolation stages for a whole
+  // chunk of cells as soon as one of them is masked, so masked cells should share chunks
+  if ((d.flags & MFGPU_HANGING_NODES) && d.constraint_mask)
+    for (auto &cells : batches)
+      std::stable_partition(cells.begin(), cells.end(), [&](uint32_t c) { return d.constraint_mask[c] != 0; });
 
   // ---- per batch: unique dofs, ordered [interior ascending | shared ascending] where interior =
   // touched by this batch only

@@ -154,8 +154,8 @@ class Mesh:
         return _view(p.value, cnt, np.uint32).reshape(-1, 4).copy()
 
     def __del__(self):
-        if getattr(self, "_h", None):
-            lib().mfgpu_mesh_destroy(self._h)
+        if getattr(self, "_h", None) and _lib is not None:  # _lib is None at interpreter shutdown
+            _lib.mfgpu_mesh_destroy(self._h)
             self._h = None
 
     # ---- numpy views of the description arrays (valid while the mesh lives)
@@ -248,8 +248,8 @@ class Plan:
         self._h = h
 
     def __del__(self):
-        if getattr(self, "_h", None):
-            lib().mfgpu_plan_destroy(self._h)
+        if getattr(self, "_h", None) and _lib is not None:
+            _lib.mfgpu_plan_destroy(self._h)
             self._h = None
 
     def _u32(self, what):
@@ -295,8 +295,8 @@ class DeviceVector:
         self.ptr = p.value
 
     def __del__(self):
-        if getattr(self, "ptr", None):
-            lib().mfgpu_vec_free(self.ptr)
+        if getattr(self, "ptr", None) and _lib is not None:
+            _lib.mfgpu_vec_free(self.ptr)
             self.ptr = None
 
     def fill(self, value, stream=None):
@@ -331,8 +331,8 @@ class Operator:
         self.clear()
 
     def clear(self):
-        if getattr(self, "_h", None):
-            lib().mfgpu_destroy(self._h)
+        if getattr(self, "_h", None) and _lib is not None:
+            _lib.mfgpu_destroy(self._h)
             self._h = None
 
     def n(self):
