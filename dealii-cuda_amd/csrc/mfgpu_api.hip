@@ -41,6 +41,7 @@ struct mfgpu_handle {
   size_t lds = 0, device_bytes = 0;
   uint32_t max_grid = 0;  // resident workgroups of the cell-loop kernel
   int stagger = 0;        // see apply_batches
+  bool plane = false;     // experimental plane-per-thread kernel (apply_planes)
   bool wave = false;      // wave-granular cell phase (apply_batches<..., WAVE = true>)
   // profiling
   bool prof = false;
@@ -163,6 +164,19 @@ int create_typed(mfgpu_handle *h, const mfgpu_desc &d) {
     set_error(std::string("coefficient fold: ") + hipGetErrorString(e));
     return MFGPU_EHIP;
   }
+  if (h->plane) {
+    ApplyArgs<T> dummy{};
+    dummy.nb_max = P.max_batch_dofs;
+    int per_cu = 0, dev = 0;
+    hipDeviceProp_t prop;
+    HIP_TRY(plane_launch<T>(P.n, dummy, nullptr, nullptr, 0, nullptr, true, &h->lds, &per_cu));
+    HIP_TRY(hipGetDevice(&dev));
+    HIP_TRY(hipGetDeviceProperties(&prop, dev));
+    h->max_grid = (uint32_t)(per_cu < 1 ? 1 : per_cu) * (uint32_t)prop.multiProcessorCount;
+    if (const char *e = getenv("MFGPU_GRID"))
+      if (atoi(e) > 0) h->max_grid = (uint32_t)atoi(e);
+    return 0;
+  }
   h->lds = apply_lds_bytes<T>(P.dim, P.n, P.max_batch_dofs, h->wave);
   if (h->lds > 160 * 1024) {
     set_error("batch needs more than 160 KiB of LDS; lower max_dofs_per_batch");
@@ -226,6 +240,10 @@ int vmult_typed(mfgpu_handle *h, void *dst, const void *src, hipStream_t st, int
       HIP_TRY(hipEventRecord(h->ev[h->ev_used], st));
     }
     a.batch_end = a.batch0 + nbat;
+    if (h->plane)
+      HIP_TRY(plane_launch<T>(P.n, a, h->S.data(), h->Dt.data(), nbat < h->max_grid ? nbat : h->max_grid, st,
+                              false, nullptr, nullptr));
+    else
     HIP_TRY(apply_launch<T>(P.dim, P.n, a, h->S.data(), h->Dt.data(), h->hn, h->twopass, h->wave,
                             nbat < h->max_grid ? nbat : h->max_grid, st));
     if (h->prof) {
@@ -273,6 +291,14 @@ int mfgpu_create(const mfgpu_desc *desc, mfgpu_handle **out) {
   mfgpu_handle *h = new mfgpu_handle();
   mfgpu_desc dplan = d;
   if (const char *e = getenv("MFGPU_WAVE")) h->wave = atoi(e) != 0;  // tuning experiments
+  if (const char *e = getenv("MFGPU_PLANE"))
+    h->plane = atoi(e) != 0 && d.dim == 3 && d.degree <= 4 && !(d.flags & MFGPU_HANGING_NODES) &&
+               !(d.flags & MFGPU_COLORED_SCATTER);
+  if (h->plane) {  // one wave per batch, one pass of 64/n cells, <= 1088 dofs
+    h->wave = false;
+    dplan.max_dofs_per_batch = 1088;
+    dplan.max_cells_per_batch = 64u / (uint32_t)(d.degree + 1);
+  }
   if (h->wave) {  // one wave per batch: smaller batches (<= 768 dofs pass through 64 x 12 registers)
     if (!dplan.max_dofs_per_batch || dplan.max_dofs_per_batch > 768) dplan.max_dofs_per_batch = 768;
     if (!dplan.max_cells_per_batch) dplan.max_cells_per_batch = 8;
@@ -405,13 +431,13 @@ int mfgpu_debug_stamps(mfgpu_handle *h, unsigned long long *out, size_t n_batche
   if (!h) return MFGPU_EINVAL;
   const size_t nbt = h->plan.batch_cell_off.size() - 1;
   if (!h->d_stamps) {
-    HIP_TRY(hipMalloc((void **)&h->d_stamps, nbt * 16 * sizeof(unsigned long long)));
-    HIP_TRY(hipMemset(h->d_stamps, 0, nbt * 16 * sizeof(unsigned long long)));
+    HIP_TRY(hipMalloc((void **)&h->d_stamps, 2 * nbt * 16 * sizeof(unsigned long long)));
+    HIP_TRY(hipMemset(h->d_stamps, 0, 2 * nbt * 16 * sizeof(unsigned long long)));
     return 0;
   }
   if (out && n_batches == nbt) {
     HIP_TRY(hipDeviceSynchronize());
-    HIP_TRY(hipMemcpy(out, h->d_stamps, nbt * 16 * sizeof(unsigned long long), hipMemcpyDeviceToHost));
+    HIP_TRY(hipMemcpy(out, h->d_stamps, 2 * nbt * 16 * sizeof(unsigned long long), hipMemcpyDeviceToHost));
   }
   return 0;
 }

@@ -51,6 +51,10 @@ hipError_t apply_occupancy(int dim, int n, bool hn, bool twopass, bool wave, siz
 template <typename T>
 hipError_t reduce_launch(T *dst, const T *src, const T *halo, const uint32_t *sdofs, const uint32_t *s_off,
                          const uint32_t *s_idx, uint32_t ns, int add, hipStream_t st);
+// experimental plane-per-thread kernel (3D, n <= 5, two-pass mode, no hanging nodes)
+template <typename T>
+hipError_t plane_launch(int n, const ApplyArgs<T> &a, const double *S, const double *Dt, uint32_t grid,
+                        hipStream_t st, bool configure_only, size_t *lds_out, int *occupancy);
 template <typename T>
 hipError_t orphan_launch(T *dst, const T *src, const uint32_t *orph, uint32_t n, int add, hipStream_t st);
 template <typename T>

@@ -141,6 +141,7 @@ __device__ __forceinline__ void lds_add(T *p, T v) {
 
 // a batch's dof list and source values pass through registers: 9 per thread at 256 threads, 12 at 64
 constexpr int max_batch_dofs(int kBlock) { return kBlock == 256 ? 2304 : 768; }
+constexpr int kMaxChunks = 3;  // chunks of cells per batch (unrolled in the kernel; planner: mfgpu_plan.cpp)
 
 // Synchronisation granularity of the cell pipeline: the transposes between two contraction stages go
 // through LDS; with whole cells owned by ONE wave they need no s_barrier, only program order.
@@ -166,13 +167,23 @@ __device__ __forceinline__ void cell_pipeline(const bool act, const int pa, cons
                                               const bool any_mask, const T *usrc, T *acc, T *Wc, T *Rc,
                                               const T *cf, const uint16_t *lm, const T *Wl,
                                               const Tables<T, n> &tab, StageNext &&stage_next,
-                                              const int dbg = 0) {
+                                              const int dbg = 0, unsigned long long *pst = nullptr) {
   constexpr int n2 = n * n;
 #ifdef MFGPU_STAMPS
 #define PDBG(bit) (dbg & (bit))
+#define PSTAMP(k)                                                                        \
+  do {                                                                                   \
+    if (pst && threadIdx.x == 0) {                                                       \
+      unsigned long long t_;                                                             \
+      asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_)::"memory");          \
+      pst[k] = t_;                                                                       \
+    }                                                                                    \
+  } while (0)
 #else
 #define PDBG(bit) 0
+#define PSTAMP(k)
 #endif
+  PSTAMP(0);
   const int bx = (dim == 3) ? n * pa + n2 * pb : n * pa;  // x-pencil, stride 1
   const int by = (dim == 3) ? pa + n2 * pb : pa;          // y-pencil, stride n
   const int bz = pa + n * pb;                             // z-pencil, stride n2 (3D only)
@@ -219,6 +230,7 @@ __device__ __forceinline__ void cell_pipeline(const bool act, const int pa, cons
       lds_store<n>(Wc + bx, 1, v);
     }
     Sync::sync();
+    PSTAMP(1);
     // P1: interpolate along y
     if (act) {
       lds_load<n>(Wc + by, n, u);
@@ -226,6 +238,7 @@ __device__ __forceinline__ void cell_pipeline(const bool act, const int pa, cons
       lds_store<n>(Wc + by, n, v);
     }
     Sync::sync();
+    PSTAMP(2);
     // P2: interpolate along z -> values at quadrature points; z-derivative part
     if (act) {
       lds_load<n>(Wc + bz, n2, u);
@@ -239,6 +252,7 @@ __device__ __forceinline__ void cell_pipeline(const bool act, const int pa, cons
       lds_store<n>(Rc + bz, n2, r);
     }
     Sync::sync();
+    PSTAMP(3);
     // P3: y-derivative part
     if (act) {
       lds_load<n>(Wc + by, n, w);
@@ -253,6 +267,7 @@ __device__ __forceinline__ void cell_pipeline(const bool act, const int pa, cons
       lds_store<n>(Rc + by, n, r);
     }
     Sync::sync();
+    PSTAMP(4);
     // P4: x-derivative part, then S^T along x
     if (act) {
       lds_load<n>(Wc + bx, 1, w);
@@ -268,6 +283,7 @@ __device__ __forceinline__ void cell_pipeline(const bool act, const int pa, cons
       lds_store<n>(Rc + bx, 1, v);
     }
     Sync::sync();
+    PSTAMP(5);
     // P5: S^T along y; coefficient / index buffers are free now (last read in P4 / at the chunk
     // start): stage the next chunk
     if (act) {
@@ -277,6 +293,7 @@ __device__ __forceinline__ void cell_pipeline(const bool act, const int pa, cons
     }
     stage_next();
     Sync::sync();
+    PSTAMP(6);
     // P6: S^T along z, scatter-add into the batch accumulator
     if (act) {
       lds_load<n>(Rc + bz, n2, u);
@@ -307,6 +324,7 @@ __device__ __forceinline__ void cell_pipeline(const bool act, const int pa, cons
 #pragma unroll
       for (int k = 0; k < n; ++k) if (!PDBG(16)) lds_add(&acc[iz[k]], v[k]); else asm volatile("" ::"v"(v[k]), "v"(iz[k]));
     }
+    PSTAMP(7);
   } else {  // dim == 2
     if (HN && any_mask) {
       bool type;
@@ -429,8 +447,8 @@ apply_batches(const ApplyArgs<T> A, const Tables<T, n> tab) {
   // phases never overlap.  Blocks are dealt round-robin over XCDs and CUs, so block b and b + 256 share a
   // CU (speed only, never correctness): delay the k-th resident workgroup of a CU by k * stagger.
   if (A.stagger > 0) {
-    const int slot = (int)(blockIdx.x / 256u);
-    for (int k = 0; k < slot * A.stagger; ++k) __builtin_amdgcn_s_sleep(127);  // 127 * 64 cycles each
+    const int slot = (int)((blockIdx.x / 256u) * 4u + ((blockIdx.x >> 3) & 3u));  // 8 phases chip-wide
+    for (int k = 0; k < slot * A.stagger; ++k) __builtin_amdgcn_s_sleep(70);  // 70 * 64 = 4480 cycles each
   }
   uint32_t c0, d0, hoff;
   int nb, ncell, nint;
@@ -552,7 +570,14 @@ apply_batches(const ApplyArgs<T> A, const Tables<T, n> tab) {
 
     // ---- 2. cells
     const int ncell_eff = DBG(1) ? 0 : ncell;
-    for (int base = 0; base < ncell_eff; base += CH) {
+    // The chunk loop is fully unrolled (a batch has at most kMaxChunks chunks, enforced by the planner):
+    // with a run-time trip count hipcc waits vmcnt(0) for every prefetched value used after the
+    // back-edge, which also waits for the long-latency gathers of the next batch; in straight-line code
+    // it emits counted waits and younger loads stay in flight.
+#pragma unroll
+    for (int k = 0; k < kMaxChunks; ++k) {
+      const int base = k * CH;
+      if (base >= ncell_eff) continue;  // uniform
       const bool act = (gtid < CH * P) && (base + lc < ncell);
       const int nxt = base + CH;
       // coefficient / index stream of the next chunk: of this batch, or the first one of the next batch
@@ -564,6 +589,9 @@ apply_batches(const ApplyArgs<T> A, const Tables<T, n> tab) {
         cnt_next = chunk_count(ncelln, 0);
         if (!DBG(8)) prefetch(c0n, cnt_next);
       }
+      // source values of the next batch: issued AFTER this chunk's stream prefetch so that the counted
+      // wait for the stream leaves these gathers in flight; their dof list was requested a chunk ago
+      if (k == 1 && has_nb) load_src(Gn, SVn);
       const T *cf = Cb + lc * nd;
       const uint16_t *lm = Lb + lc * nd;
       unsigned mask = 0;
@@ -579,11 +607,17 @@ apply_batches(const ApplyArgs<T> A, const Tables<T, n> tab) {
       if (WAVE)
         cell_pipeline<dim, n, T, HN, WaveSync>(act, pa, pb, mask, any_mask, usrc, acc, Wc, Rc, cf, lm, Wl, tab, stage_next, A.dbg);
       else
-        cell_pipeline<dim, n, T, HN, WgSync>(act, pa, pb, mask, any_mask, usrc, acc, Wc, Rc, cf, lm, Wl, tab, stage_next, A.dbg);
+        cell_pipeline<dim, n, T, HN, WgSync>(act, pa, pb, mask, any_mask, usrc, acc, Wc, Rc, cf, lm, Wl, tab, stage_next, A.dbg,
+#ifdef MFGPU_STAMPS
+                                             (A.stamps && k == 1) ? A.stamps + (size_t)(bend + b) * 16 : nullptr
+#else
+                                             nullptr
+#endif
+        );
       // Wc is next written in P0 of the following chunk and was last read in P4 (P2 in 2D); Rc is next
       // written in P2 (P1) and was last read before the scatter-add: both separated by barriers.
-      if (base == 0 && has_nb) load_src(Gn, SVn);  // the next batch's dof list has landed by now
-      STAMP(4 + (base / CH < 8 ? base / CH : 8));
+      if (k == 0 && ncell_eff <= CH && has_nb) load_src(Gn, SVn);  // single-chunk batch
+      STAMP(4 + k);
     }
     if (ncell_eff == 0 && has_nb) {  // diagnostic builds only (cells skipped)
       prefetch(c0n, chunk_count(ncelln, 0));
@@ -667,6 +701,311 @@ reduce_shared(T *__restrict__ dst, const T *__restrict__ src, const T *__restric
     for (uint32_t j = j0 + 1; j < j1; ++j) val += halo[s_idx[j]];
   }
   dst[g] = add ? dst[g] + val : val;
+}
+
+// =============================================================================================
+// Plane kernel (3D, n <= 5, no hanging nodes): a thread owns a 2D PLANE of the cell (n*n values in
+// registers), so two of the three contraction directions are register mat-vecs and a cell needs 3
+// LDS transposes instead of the pencil pipeline's 7 (about 66 instead of 145 LDS cycles per cell; the
+// pencil pipeline is LDS-throughput bound, profiles/r01_notes.md).  One wave = one workgroup = one
+// batch of up to CW = 64/n cells processed in ONE pass (n threads per cell):
+//   A (xy-plane, z = t): gather, S_x, S_y                         -> W
+//   B (xz-plane, y = t): S_z -> w;  r_B = D_z^T c D_z w + D_x^T c D_x w   -> W (w), R (r_B)
+//   A                  : r = r_B + D_y^T c D_y w;  S_y^T, S_x^T   -> W
+//   B                  : S_z^T, add into the batch accumulator
+// The batch arrays usrc / acc alias (every gather happens in the first stage).  The coefficient is read
+// straight from global memory in both layouts (25 contiguous doubles per thread in A, 5 runs of 5 in B).
+template <int n, int sgn, bool TRANS, int DIR, typename T>
+__device__ __forceinline__ void plane_mv(const T *__restrict__ M, const T (&in)[n * n], T (&out)[n * n]) {
+  // out[q along DIR] = sum_k m(q,k) in[k along DIR],  m(q,k) = TRANS ? M[k][q] : M[q][k]
+#pragma unroll
+  for (int o = 0; o < n; ++o)  // index of the other in-plane direction
+#pragma unroll
+    for (int q = 0; q < n; ++q) {
+      T t = T(0);
+#pragma unroll
+      for (int k = 0; k < n; ++k) {
+        const T m = TRANS ? tab_at<n, sgn>(M, k, q) : tab_at<n, sgn>(M, q, k);
+        const int idx = DIR == 0 ? k + n * o : o + n * k;
+        t = (k == 0) ? m * in[idx] : fma(m, in[idx], t);
+      }
+      out[DIR == 0 ? q + n * o : o + n * q] = t;
+    }
+}
+
+constexpr int kPlaneMaxDofs = 1088;  // 17 x 64: a batch's dof list / source values pass through registers
+
+template <int n, typename T, bool TWOPASS>
+__global__ void __launch_bounds__(64)
+apply_planes(const ApplyArgs<T> A, const Tables<T, n> tab) {
+  constexpr int nd = n * n * n, n2 = n * n;
+  constexpr int CW = 64 / n;  // cells per pass
+  constexpr int kGU = kPlaneMaxDofs / 64;
+  constexpr int PL = (CW * nd + 63) / 64;  // index-map items per lane
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+  T *buf = reinterpret_cast<T *>(smem_raw);  // usrc, then acc
+  T *Wb = buf + A.nb_max;
+  T *Rb = Wb + CW * nd;
+  uint16_t *Lb = reinterpret_cast<uint16_t *>(Rb + CW * nd);
+
+  const int lane = threadIdx.x;
+  const int lc = lane / n, t = lane - lc * n;
+  const uint32_t bend = A.batch_end;
+  uint32_t b = A.batch0 + blockIdx.x;
+  if (b >= bend) return;
+  T *Wc = Wb + lc * nd;
+  T *Rc = Rb + lc * nd;
+  const uint16_t *lm = Lb + lc * nd;
+
+  auto load_dofs = [&](uint32_t d0_, int nb_, uint32_t (&g_)[kGU]) {
+#pragma unroll
+    for (int j = 0; j < kGU; ++j) {
+      const int tt = lane + j * 64;
+      g_[j] = DBG(16) ? (uint32_t)tt : A.bdofs[d0_ + (tt < nb_ ? tt : nb_ - 1)];
+    }
+  };
+  auto load_src = [&](const uint32_t (&g_)[kGU], T (&sv_)[kGU]) {
+#pragma unroll
+    for (int j = 0; j < kGU; ++j) sv_[j] = DBG(2) ? T(1) : A.src[g_[j] & 0x7fffffffu];
+  };
+  uint32_t c0 = A.batch_cell_off[b], d0 = A.batch_dof_off[b];
+  int ncell = (int)(A.batch_cell_off[b + 1] - c0), nb = (int)(A.batch_dof_off[b + 1] - d0);
+  int nint = TWOPASS ? (int)A.batch_nint[b] : 0;
+  uint32_t hoff = TWOPASS ? A.halo_off[b] : 0u;
+  uint32_t G[kGU];
+  T SV[kGU];
+  uint16_t pl[PL];
+  T cB[n2], cA[n2];
+  auto load_lmap = [&](uint32_t c0_, int ncell_, uint16_t (&pl_)[PL]) {
+    const uint16_t *lg = A.lmap + (size_t)c0_ * nd;
+    const int cnt = ncell_ * nd;
+#pragma unroll
+    for (int j = 0; j < PL; ++j) {
+      const int i = lane + j * 64;
+      pl_[j] = DBG(8) ? (uint16_t)(i & 255) : lg[i < cnt ? i : cnt - 1];
+    }
+  };
+  auto load_coef = [&](uint32_t c0_, int ncell_) {
+    // coefficient planes of this thread's cell, straight from global memory in both layouts
+    const T *cf = A.coef + ((size_t)c0_ + (lc < ncell_ ? lc : 0)) * nd;
+#pragma unroll
+    for (int z = 0; z < n; ++z)
+#pragma unroll
+      for (int x = 0; x < n; ++x) cB[x + n * z] = DBG(8) ? T(1) : cf[x + n * t + n2 * z];
+#pragma unroll
+    for (int i = 0; i < n2; ++i) cA[i] = DBG(8) ? T(1) : cf[n2 * t + i];
+  };
+  load_dofs(d0, nb, G);
+  load_lmap(c0, ncell, pl);
+  load_src(G, SV);
+  load_coef(c0, ncell);
+
+  // Software pipeline over batches with the whole next batch in flight.  Issue points are chosen so
+  // that every use of a prefetched register finds only OLD loads outstanding (hipcc waits vmcnt(0)
+  // after the loop back-edge): at the top {next dof list, next index map}; after stage 3 {next source
+  // values, next coefficient planes -- into the registers stages 2 and 3 have just consumed}.
+  while (true) {
+    STAMP(0);
+    const bool act = lane < CW * n && lc < ncell;
+    STAMP(1);
+    // gathered source values -> LDS (constrained rows read as zero; the owning batch writes dst = src)
+#pragma unroll
+    for (int j = 0; j < kGU; ++j) {
+      const int tt = lane + j * 64;
+      const bool con = (G[j] >> 31) != 0;
+      if (tt < nb) {
+        buf[tt] = con ? T(0) : SV[j];
+        const bool owner = TWOPASS ? (tt < nint) : false;
+        if (con && owner) {
+          T *d = A.dst + (G[j] & 0x7fffffffu);
+          *d = A.add ? *d + SV[j] : SV[j];
+        }
+      }
+    }
+#pragma unroll
+    for (int j = 0; j < PL; ++j) {
+      const int i = lane + j * 64;
+      if (i < ncell * nd) Lb[i] = pl[j];
+    }
+    // next batch of this wave: dof list now, source values after the first stage
+    const uint32_t bn = b + gridDim.x;
+    const bool has_nb = bn < bend;
+    uint32_t c0n = c0, d0n = d0, hoffn = hoff;
+    int ncelln = ncell, nbn = nb, nintn = nint;
+    uint32_t Gn[kGU];
+    T SVn[kGU];
+    uint16_t pln[PL];
+    if (has_nb) {
+      c0n = A.batch_cell_off[bn];
+      ncelln = (int)(A.batch_cell_off[bn + 1] - c0n);
+      d0n = A.batch_dof_off[bn];
+      nbn = (int)(A.batch_dof_off[bn + 1] - d0n);
+      nintn = TWOPASS ? (int)A.batch_nint[bn] : 0;
+      hoffn = TWOPASS ? A.halo_off[bn] : 0u;
+      load_dofs(d0n, nbn, Gn);
+      load_lmap(c0n, ncelln, pln);
+    }
+    WaveSync::sync();
+    STAMP(2);  // gathered values + index map in LDS (waited for SV, pl)
+
+    T u[n2], v[n2];
+    // ---- stage 1, layout A (z = t): gather, S_x, S_y
+    if (act) {
+#pragma unroll
+      for (int i = 0; i < n2; ++i) u[i] = buf[lm[n2 * t + i]];
+      plane_mv<n, 1, true, 0>(tab.S, u, v);
+      plane_mv<n, 1, true, 1>(tab.S, v, u);
+#pragma unroll
+      for (int i = 0; i < n2; ++i) Wc[n2 * t + i] = u[i];
+    }
+    WaveSync::sync();
+    STAMP(3);  // stage 1 done
+    // every gather is done: the batch array becomes the accumulator
+#pragma unroll
+    for (int j = 0; j < kGU; ++j) {
+      const int tt = lane + j * 64;
+      if (tt < nb) buf[tt] = T(0);
+    }
+    // ---- stage 2, layout B (y = t): S_z; z- and x-derivative parts
+    T w[n2], r[n2];
+    if (act) {
+#pragma unroll
+      for (int z = 0; z < n; ++z)
+#pragma unroll
+        for (int x = 0; x < n; ++x) u[x + n * z] = Wc[x + n * t + n2 * z];
+      plane_mv<n, 1, true, 1>(tab.S, u, w);  // values at the quadrature points
+      plane_mv<n, -1, false, 1>(tab.Dt, w, u);
+#pragma unroll
+      for (int i = 0; i < n2; ++i) u[i] *= cB[i];
+      plane_mv<n, -1, true, 1>(tab.Dt, u, r);
+      plane_mv<n, -1, false, 0>(tab.Dt, w, u);
+#pragma unroll
+      for (int i = 0; i < n2; ++i) u[i] *= cB[i];
+      plane_mv<n, -1, true, 0>(tab.Dt, u, v);
+#pragma unroll
+      for (int z = 0; z < n; ++z)
+#pragma unroll
+        for (int x = 0; x < n; ++x) {
+          Wc[x + n * t + n2 * z] = w[x + n * z];
+          Rc[x + n * t + n2 * z] = r[x + n * z] + v[x + n * z];
+        }
+    }
+    WaveSync::sync();
+    STAMP(4);  // stage 2 done (waited for cB)
+    // ---- stage 3, layout A: y-derivative part, S_y^T, S_x^T
+    if (act) {
+#pragma unroll
+      for (int i = 0; i < n2; ++i) {
+        w[i] = Wc[n2 * t + i];
+        r[i] = Rc[n2 * t + i];
+      }
+      plane_mv<n, -1, false, 1>(tab.Dt, w, u);
+#pragma unroll
+      for (int i = 0; i < n2; ++i) u[i] *= cA[i];
+      plane_mv<n, -1, true, 1>(tab.Dt, u, v);
+#pragma unroll
+      for (int i = 0; i < n2; ++i) v[i] += r[i];
+      plane_mv<n, 1, false, 1>(tab.S, v, u);
+      plane_mv<n, 1, false, 0>(tab.S, u, v);
+#pragma unroll
+      for (int i = 0; i < n2; ++i) Wc[n2 * t + i] = v[i];
+    }
+    WaveSync::sync();
+    if (has_nb) {  // the rest of the next batch: source values, coefficient planes
+      load_src(Gn, SVn);
+      load_coef(c0n, ncelln);
+    }
+    STAMP(5);  // stage 3 done
+    // ---- stage 4, layout B: S_z^T, add into the batch accumulator
+    if (act) {
+#pragma unroll
+      for (int z = 0; z < n; ++z)
+#pragma unroll
+        for (int x = 0; x < n; ++x) u[x + n * z] = Wc[x + n * t + n2 * z];
+      plane_mv<n, 1, false, 1>(tab.S, u, v);
+#pragma unroll
+      for (int z = 0; z < n; ++z)
+#pragma unroll
+        for (int x = 0; x < n; ++x) lds_add(&buf[lm[x + n * t + n2 * z]], v[x + n * z]);
+    }
+    WaveSync::sync();
+    STAMP(6);  // stage 4 done
+    // ---- scatter: interior dofs -> dst, shared dofs -> halo slots (two-pass mode only)
+    {
+      T *halo = A.halo + hoff;
+      T old[kGU];
+      if (A.add) {
+#pragma unroll
+        for (int j = 0; j < kGU; ++j) old[j] = A.dst[G[j] & 0x7fffffffu];
+      }
+#pragma unroll
+      for (int j = 0; j < kGU; ++j) {
+        const int tt = lane + j * 64;
+        if (DBG(4)) {
+          asm volatile("" ::"v"(buf[tt < nb ? tt : 0]));
+        } else if (tt < nint) {
+          if (!(G[j] >> 31)) A.dst[G[j]] = A.add ? old[j] + buf[tt] : buf[tt];
+        } else if (tt < nb) {
+          halo[tt - nint] = buf[tt];
+        }
+      }
+    }
+    STAMP(7);  // scatter issued
+    if (!has_nb) break;
+    WaveSync::sync();  // buf / Lb are rewritten for the next batch
+    b = bn;
+    c0 = c0n;
+    ncell = ncelln;
+    d0 = d0n;
+    nb = nbn;
+    nint = nintn;
+    hoff = hoffn;
+#pragma unroll
+    for (int j = 0; j < kGU; ++j) {
+      G[j] = Gn[j];
+      SV[j] = SVn[j];
+    }
+#pragma unroll
+    for (int j = 0; j < PL; ++j) pl[j] = pln[j];
+  }
+}
+
+template <int n, typename T>
+static size_t plane_lds_bytes(uint32_t nb_max) {
+  constexpr int nd = n * n * n, CW = 64 / n;
+  return (size_t)(nb_max + 2 * CW * nd) * sizeof(T) + (size_t)CW * nd * sizeof(uint16_t);
+}
+
+template <typename T>
+hipError_t plane_launch(int n, const ApplyArgs<T> &a, const double *S, const double *Dt, uint32_t grid,
+                        hipStream_t st, bool configure_only, size_t *lds_out, int *occupancy) {
+#define PLANE_CASE(N)                                                                                       \
+  case N: {                                                                                                 \
+    const size_t lds = plane_lds_bytes<N, T>(a.nb_max);                                                     \
+    if (lds_out) *lds_out = lds;                                                                            \
+    if (configure_only) {                                                                                   \
+      hipError_t e = hipFuncSetAttribute((const void *)apply_planes<N, T, true>,                            \
+                                         hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);            \
+      if (e == hipSuccess && occupancy)                                                                     \
+        e = hipOccupancyMaxActiveBlocksPerMultiprocessor(occupancy, apply_planes<N, T, true>, 64, lds);     \
+      return e;                                                                                             \
+    }                                                                                                       \
+    Tables<T, N> tab;                                                                                       \
+    for (int i = 0; i < ((N + 1) / 2) * N; ++i) {                                                           \
+      tab.S[i] = (T)S[i];                                                                                   \
+      tab.Dt[i] = (T)Dt[i];                                                                                 \
+    }                                                                                                       \
+    hipLaunchKernelGGL((apply_planes<N, T, true>), dim3(grid), dim3(64), lds, st, a, tab);                  \
+    return hipGetLastError();                                                                               \
+  }
+  switch (n) {
+    PLANE_CASE(2)
+    PLANE_CASE(3)
+    PLANE_CASE(4)
+    PLANE_CASE(5)
+    default: return hipErrorInvalidValue;
+  }
+#undef PLANE_CASE
 }
 
 // dofs no cell touches (e.g. hanging nodes eliminated from loc2glob): vmult gives
@@ -888,6 +1227,8 @@ hipError_t fill_launch(T *v, size_t n, T a, hipStream_t st) {
 }
 
 #define INST(T)                                                                                         \
+  template hipError_t plane_launch<T>(int, const ApplyArgs<T> &, const double *, const double *, uint32_t, \
+                                      hipStream_t, bool, size_t *, int *);                              \
   template size_t apply_lds_bytes<T>(int, int, uint32_t, bool);                                         \
   template hipError_t apply_configure<T>(int, int, size_t, bool);                                       \
   template hipError_t apply_occupancy<T>(int, int, bool, bool, bool, size_t, int *);                    \

@@ -75,6 +75,10 @@ static void default_batch_limits(const mfgpu_desc &d, uint32_t &max_cells, uint3
     const uint32_t cap = std::max<uint32_t>(1u, d.n_cells / 4096u);
     max_cells = std::min(max_cells, cap);
   }
+  // the kernel unrolls at most 3 chunks of CH = threads / n^(dim-1) cells per batch (mfgpu_kernels.hip)
+  const uint32_t threads = d.max_dofs_per_batch && d.max_dofs_per_batch <= 768 ? 64u : 256u;
+  const uint32_t ch = std::max<uint32_t>(1u, threads / (uint32_t)ipow(p + 1, dim - 1));
+  max_cells = std::min(max_cells, 3u * ch);
   if (max_cells < 1) max_cells = 1;
 }
 

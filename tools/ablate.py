@@ -29,6 +29,6 @@ if len(sys.argv) > 1 and sys.argv[1] == "child":
 else:
     n = int(sys.argv[1]) if len(sys.argv) > 1 else 54
     for bc in (int(os.environ.get("ABL_BC", "27")),):
-        for dbg in (0, 16, 32, 48, 14, 14+16, 14+48):
+        for dbg in [int(x) for x in os.environ.get("ABL_DBG", "0,2,8,4,10,14,30").split(",")]:
             env = dict(os.environ, MFGPU_DBG=str(dbg))
             subprocess.run([sys.executable, __file__, "child", str(n), str(bc)], env=env)

@@ -29,11 +29,15 @@ for i in range(3):
     dst.swap(src)
     op.vmult(dst, src)
 mf.synchronize()
-buf = np.zeros(nbt * 16, dtype=np.uint64)
+buf = np.zeros(2 * nbt * 16, dtype=np.uint64)
 assert L.mfgpu_debug_stamps(op._h, buf.ctypes.data, nbt) == 0
-S = buf.reshape(nbt, 16).astype(np.int64)
+S = buf[:nbt * 16].reshape(nbt, 16).astype(np.int64)
+PS = buf[nbt * 16:].reshape(nbt, 16).astype(np.int64)
 print("plan", st)
-names = {0: "entry", 2: "src gathered", 3: "gather barrier", 4: "chunk0 done", 5: "chunk1 done",
+plane = os.environ.get("MFGPU_PLANE") == "1"
+names = {0: "entry", 1: "loads issued", 2: "gathered->LDS (wait SV, lmap)", 3: "stage 1 (A: gather, S_x, S_y)",
+         4: "stage 2 (B: S_z, D_z, D_x; wait cB)", 5: "stage 3 (A: D_y, S^T; wait cA)", 6: "stage 4 (B: S_z^T, acc)",
+         7: "scatter issued"} if plane else {0: "entry", 2: "src gathered", 3: "gather barrier", 4: "chunk0 done", 5: "chunk1 done",
          6: "chunk2 done", 7: "chunk3 done", 13: "all chunks+barrier", 15: "scatter drained"}
 used = [k for k in sorted(names) if (S[:, k] != 0).any()]
 prev = used[0]
@@ -49,3 +53,13 @@ e = S[:nb0, 0] - S[:nb0, 0].min()
 x = S[:nb0, 15] - S[:nb0, 0].min()
 print(f"colour 0: {nb0} workgroups; start offsets p50 {np.percentile(e,50):.0f} p90 {np.percentile(e,90):.0f} max {e.max():.0f};"
       f" end max {x.max():.0f} cyc")
+
+# per-stage stamps of the SECOND chunk of every batch (3D): P0 .. P6
+ok = (PS[:, 0] != 0) & (PS[:, 7] != 0)
+if ok.any():
+    names = ["P0 gather+S_x", "P1 S_y", "P2 S_z,D_z", "P3 D_y", "P4 D_x,S_x^T", "P5 S_y^T+stage", "P6 S_z^T+acc"]
+    tot = (PS[ok, 7] - PS[ok, 0]).mean()
+    print(f"second chunk, stage shares (wave 0, {ok.sum()} batches), total {tot:.0f} cyc:")
+    for k in range(7):
+        d = PS[ok, k + 1] - PS[ok, k]
+        print(f"  {names[k]:>16s} mean {d.mean():7.0f} cyc ({100*d.mean()/tot:4.1f} %)  p90 {np.percentile(d,90):7.0f}")
