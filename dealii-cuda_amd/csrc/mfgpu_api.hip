@@ -42,6 +42,7 @@ struct mfgpu_handle {
   uint32_t max_grid = 0;  // resident workgroups of the cell-loop kernel
   int stagger = 0;        // see apply_batches
   bool plane = false;     // experimental plane-per-thread kernel (apply_planes)
+  bool ls = false;        // loader / compute specialised cell loop (apply_batches_ls)
   bool wave = false;      // wave-granular cell phase (apply_batches<..., WAVE = true>)
   // profiling
   bool prof = false;
@@ -177,6 +178,24 @@ int create_typed(mfgpu_handle *h, const mfgpu_desc &d) {
       if (atoi(e) > 0) h->max_grid = (uint32_t)atoi(e);
     return 0;
   }
+  if (h->ls) {
+    ApplyArgs<T> dummy{};
+    dummy.nb_max = P.max_batch_dofs;
+    int per_cu = 0, dev = 0;
+    hipDeviceProp_t prop;
+    HIP_TRY(ls_launch<T>(P.dim, P.n, dummy, nullptr, nullptr, h->hn, 0, nullptr, true, &h->lds, nullptr));
+    if (h->lds > 160 * 1024) {
+      set_error("batch needs more than 160 KiB of LDS; lower max_dofs_per_batch");
+      return MFGPU_EINVAL;
+    }
+    HIP_TRY(ls_launch<T>(P.dim, P.n, dummy, nullptr, nullptr, h->hn, 0, nullptr, true, &h->lds, &per_cu));
+    HIP_TRY(hipGetDevice(&dev));
+    HIP_TRY(hipGetDeviceProperties(&prop, dev));
+    h->max_grid = (uint32_t)(per_cu < 1 ? 1 : per_cu) * (uint32_t)prop.multiProcessorCount;
+    if (const char *e = getenv("MFGPU_GRID"))
+      if (atoi(e) > 0) h->max_grid = (uint32_t)atoi(e);
+    return 0;
+  }
   h->lds = apply_lds_bytes<T>(P.dim, P.n, P.max_batch_dofs, h->wave);
   if (h->lds > 160 * 1024) {
     set_error("batch needs more than 160 KiB of LDS; lower max_dofs_per_batch");
@@ -240,7 +259,10 @@ int vmult_typed(mfgpu_handle *h, void *dst, const void *src, hipStream_t st, int
       HIP_TRY(hipEventRecord(h->ev[h->ev_used], st));
     }
     a.batch_end = a.batch0 + nbat;
-    if (h->plane)
+    if (h->ls)
+      HIP_TRY(ls_launch<T>(P.dim, P.n, a, h->S.data(), h->Dt.data(), h->hn, nbat < h->max_grid ? nbat : h->max_grid,
+                           st, false, nullptr, nullptr));
+    else if (h->plane)
       HIP_TRY(plane_launch<T>(P.n, a, h->S.data(), h->Dt.data(), nbat < h->max_grid ? nbat : h->max_grid, st,
                               false, nullptr, nullptr));
     else
@@ -303,6 +325,9 @@ int mfgpu_create(const mfgpu_desc *desc, mfgpu_handle **out) {
     if (!dplan.max_dofs_per_batch || dplan.max_dofs_per_batch > 768) dplan.max_dofs_per_batch = 768;
     if (!dplan.max_cells_per_batch) dplan.max_cells_per_batch = 8;
   }
+  // experimental loader / compute wave split (slower than apply_batches: profiles/r01_notes.md)
+  if (const char *e = getenv("MFGPU_LS"))
+    h->ls = atoi(e) != 0 && !h->wave && !h->plane && !(d.flags & MFGPU_COLORED_SCATTER);
   int rc = build_plan(dplan, h->plan);
   if (rc) {
     delete h;

@@ -55,6 +55,10 @@ hipError_t reduce_launch(T *dst, const T *src, const T *halo, const uint32_t *sd
 template <typename T>
 hipError_t plane_launch(int n, const ApplyArgs<T> &a, const double *S, const double *Dt, uint32_t grid,
                         hipStream_t st, bool configure_only, size_t *lds_out, int *occupancy);
+// loader / compute specialised cell loop (mfgpu_kernels_ls.hip; two-pass mode)
+template <typename T>
+hipError_t ls_launch(int dim, int n, const ApplyArgs<T> &a, const double *S, const double *Dt, bool hn,
+                     uint32_t grid, hipStream_t st, bool configure_only, size_t *lds_out, int *occupancy);
 template <typename T>
 hipError_t orphan_launch(T *dst, const T *src, const uint32_t *orph, uint32_t n, int add, hipStream_t st);
 template <typename T>

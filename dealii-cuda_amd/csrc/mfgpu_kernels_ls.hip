@@ -1,14 +1,17 @@
-// Loader / compute specialised cell-loop kernel (two-pass scatter mode).
+// Loader / compute specialised cell-loop kernel (two-pass scatter mode).  EXPERIMENTAL (MFGPU_LS=1):
+// parity-green, but slower than apply_batches on MI355X (0.285 vs 0.196 ms per launch on the p=4 bench
+// workload): two loader waves, capped at 168 VGPRs by the 3 waves/SIMD the layout needs, cannot keep
+// enough bytes in flight per CU, so the loaders become the latency-bound stage (profiles/r01_notes.md).
 //
 // A workgroup has 6 waves: 4 COMPUTE waves run the cell pipeline (mfgpu_cell.cuh) on LDS data only --
 // they never issue a global memory instruction and therefore never wait on vmcnt -- and 2 LOADER waves
 // own every global load and store of the workgroup's batches:
-//   * dof list of batch b+2, source values of batch b+1 (gather, read_dof_values fee_gpu.cuh:323-331)
-//     and the coefficient / index stream of the next chunk are in flight while batch b is computed,
+//   * dof list and source values of batch b+1 (gather, read_dof_values fee_gpu.cuh:323-331) and the
+//     coefficient / index stream of the next chunk are in flight while batch b is computed,
 //   * the values reach LDS (usrc, Cb, Lb, Mb) at points of the pipeline where the buffers are dead,
 //   * after the batch's last cell the loaders move the accumulator to dst / the halo buffer
 //     (distribute_local_to_global fee_gpu.cuh:346-363, one write per batch dof) and clear it.
-// Every value a loader waits for was requested at least one chunk (normally one batch) earlier, so the
+// Every value a loader waits for was requested about one chunk (several microseconds) earlier, so the
 // loaders arrive at the pipeline's barriers without stalling the compute waves, and memory latency is
 // decoupled from the LDS / VALU work.  In apply_batches (all waves do both) the compiler's in-order
 // vmcnt waits made the memory and the cell phase of a workgroup add up (profiles/r01_notes.md).
@@ -102,6 +105,14 @@ apply_batches_ls(const ApplyArgs<T> A, const Tables<T, n> tab) {
   if (tid >= kLsCompute) {
     // =========================================================================== loader waves
     const int lt = tid - kLsCompute;
+    // hipcc hoists the per-lane constants lt + j * 128 of every unrolled helper loop out of the batch loop
+    // and keeps all of them live (18 VGPRs per helper, then spills the dof lists): an opaque copy of the
+    // lane index makes them one-instruction temporaries
+    auto lane = [&]() {
+      int l = lt;
+      asm volatile("" : "+v"(l));
+      return l;
+    };
     struct Meta {
       uint32_t c0, d0, hoff;
       int ncell, nb, nint;
@@ -118,10 +129,12 @@ apply_batches_ls(const ApplyArgs<T> A, const Tables<T, n> tab) {
     };
     // all loads unconditional on clamped indices (a predicated load costs a branch and a full wait)
     auto load_dofs = [&](const Meta &m, uint32_t (&g)[kGL]) {
+      const int l = lane();
+      const uint32_t *bd = A.bdofs + m.d0;
 #pragma unroll
       for (int j = 0; j < kGL; ++j) {
-        const int t = lt + j * kLsLoader;
-        g[j] = A.bdofs[m.d0 + (t < m.nb ? t : m.nb - 1)];
+        const int t = l + j * kLsLoader;
+        g[j] = bd[t < m.nb ? t : m.nb - 1];
       }
     };
     auto load_src = [&](const uint32_t (&g)[kGL], T (&sv)[kGL]) {
@@ -131,13 +144,14 @@ apply_batches_ls(const ApplyArgs<T> A, const Tables<T, n> tab) {
     // gather result -> LDS.  bdofs bit 31 = constrained row: reads as 0 (constraint_handler_gpu.cu:258-259)
     // and, if this batch owns the row, dst = src (identity rows, :286).
     auto write_usrc = [&](const uint32_t (&g)[kGL], const T (&sv)[kGL], const Meta &m) {
+      const int l = lane();
+      T *ul = usrc + l;
 #pragma unroll
       for (int j = 0; j < kGL; ++j) {
-        const int t = lt + j * kLsLoader;
         const bool con = (g[j] >> 31) != 0;
-        if (t < m.nb) {
-          usrc[t] = con ? T(0) : sv[j];
-          if (con && t < m.nint) {
+        if (l < m.nb - j * kLsLoader) {
+          ul[j * kLsLoader] = con ? T(0) : sv[j];
+          if (con && l < m.nint - j * kLsLoader) {
             T *d = A.dst + (g[j] & 0x7fffffffu);
             *d = A.add ? *d + sv[j] : sv[j];
           }
@@ -147,20 +161,21 @@ apply_batches_ls(const ApplyArgs<T> A, const Tables<T, n> tab) {
     // accumulator -> dst (interior dofs: this batch alone touches them) / halo (partial sums of shared
     // dofs, summed by reduce_shared); clears the accumulator for the next batch
     auto scatter = [&](const uint32_t (&g)[kGL], const Meta &m) {
-      T *halo = A.halo + m.hoff;
+      const int l = lane();
+      T *al = acc + l;
+      T *hl = A.halo + m.hoff + l - m.nint;
 #pragma unroll
       for (int j = 0; j < kGL; ++j) {
-        const int t = lt + j * kLsLoader;
-        if (t < (int)A.nb_max) {
-          const T v = acc[t];
-          acc[t] = T(0);
-          if (t < m.nint) {
+        if (l < (int)A.nb_max - j * kLsLoader) {
+          const T v = al[j * kLsLoader];
+          al[j * kLsLoader] = T(0);
+          if (l < m.nint - j * kLsLoader) {
             if (!(g[j] >> 31)) {
               T *d = A.dst + g[j];
               *d = A.add ? *d + v : v;
             }
-          } else if (t < m.nb) {
-            halo[t - m.nint] = v;  // constrained shared dofs: value ignored by reduce_shared
+          } else if (l < m.nb - j * kLsLoader) {
+            hl[j * kLsLoader] = v;  // constrained shared dofs: value ignored by reduce_shared
           }
         }
       }
@@ -172,23 +187,26 @@ apply_batches_ls(const ApplyArgs<T> A, const Tables<T, n> tab) {
       const T *cg = A.coef + (size_t)cell0 * nd;
       const uint16_t *lg = A.lmap + (size_t)cell0 * nd;
       const int cnt = cells * nd;
+      const int l = lane();
 #pragma unroll
       for (int j = 0; j < PFL; ++j) {
-        const int i = lt + j * kLsLoader;
+        const int i = l + j * kLsLoader;
         const int ic = i < cnt ? i : cnt - 1;
         pc[j] = cg[ic];
         pl[j] = lg[ic];
       }
-      if (HN) pm = A.cmask[(size_t)cell0 + (lt < cells ? lt : cells - 1)];
+      if (HN) pm = A.cmask[(size_t)cell0 + (l < cells ? l : cells - 1)];
     };
     auto stage = [&](int cells) {
       const int cnt = cells * nd;
+      const int l = lane();
+      T *cl = Cb + l;
+      uint16_t *ll = Lb + l;
 #pragma unroll
       for (int j = 0; j < PFL; ++j) {
-        const int i = lt + j * kLsLoader;
-        if (i < cnt) {
-          Cb[i] = pc[j];
-          Lb[i] = pl[j];
+        if (l < cnt - j * kLsLoader) {
+          cl[j * kLsLoader] = pc[j];
+          ll[j * kLsLoader] = pl[j];
         }
       }
       if (HN) {
@@ -210,15 +228,14 @@ apply_batches_ls(const ApplyArgs<T> A, const Tables<T, n> tab) {
     bool has_nb = b + stride < bend;
     Meta m = load_meta(b);
     Meta mn = has_nb ? load_meta(b + stride) : m;
-    uint32_t G[kGL], Gn[kGL], Gnn[kGL];
+    uint32_t G[kGL], Gn[kGL];
     T SVn[kGL];
     load_dofs(m, G);
-    load_dofs(mn, Gn);
     prefetch(m.c0, m.ncell < CH ? m.ncell : CH);
     load_src(G, SVn);
 #pragma unroll
     for (int j = 0; j < kGL; ++j) {
-      Gnn[j] = 0;
+      Gn[j] = 0;
       const int t = lt + j * kLsLoader;
       if (t < (int)A.nb_max) acc[t] = T(0);
     }
@@ -231,9 +248,8 @@ apply_batches_ls(const ApplyArgs<T> A, const Tables<T, n> tab) {
     while (true) {
       __syncthreads();  // batch b is staged: the compute waves start
       const bool has_nnb = has_nb && (b + 2 * stride < bend);
-      Meta mnn = has_nnb ? load_meta(b + 2 * stride) : mn;
-      if (has_nb) load_src(Gn, SVn);       // its dof list was requested a batch ago
-      if (has_nnb) load_dofs(mnn, Gnn);    // two batches ahead
+      const Meta mnn = has_nnb ? load_meta(b + 2 * stride) : mn;  // scalar loads, used at the rotation
+      if (has_nb) load_dofs(mn, Gn);
 #pragma unroll
       for (int k = 0; k < kMaxChunks; ++k) {
         const int base = k * CH;
@@ -250,12 +266,13 @@ apply_batches_ls(const ApplyArgs<T> A, const Tables<T, n> tab) {
         }
         const bool any_mask = HN ? ((Mb[CH] | Mb[CH + 1]) != 0) : false;
         loader_shadow<dim, HN>(
-            any_mask,
-            [&]() {
-              if (last && has_nb) write_usrc(Gn, SVn, mn);  // every gather of batch b has happened
-            },
+            any_mask, []() {},
             [&]() {
               if (cells_next > 0) stage(cells_next);
+              // next batch: gather once its dof list (requested at the top of chunk 0) is here; the values
+              // reach LDS a batch's last chunk later (usrc is dead after that chunk's first barrier)
+              if (k == 0 && has_nb) load_src(Gn, SVn);
+              if (last && has_nb) write_usrc(Gn, SVn, mn);
             });
       }
       __syncthreads();  // accumulator complete
@@ -267,10 +284,7 @@ apply_batches_ls(const ApplyArgs<T> A, const Tables<T, n> tab) {
       m = mn;
       mn = mnn;
 #pragma unroll
-      for (int j = 0; j < kGL; ++j) {
-        G[j] = Gn[j];
-        Gn[j] = Gnn[j];
-      }
+      for (int j = 0; j < kGL; ++j) G[j] = Gn[j];
     }
   } else {
     // =========================================================================== compute waves

@@ -56,6 +56,21 @@ def test_vmult_matches_oracle(dim, p, n, nt, colored):
     assert rel(y, o.vmult(od, x.astype(mf.np_dtype(nt)).astype(np.float64))) <= TOL[nt]
 
 
+@pytest.mark.parametrize("knob", ["MFGPU_LS", "MFGPU_WAVE", "MFGPU_PLANE"])
+@pytest.mark.parametrize("dim,p,n", [(3, 4, 7), (3, 2, 9), (2, 3, 12)])
+def test_experimental_kernel_variants_match_oracle(knob, dim, p, n, monkeypatch):
+    """The opt-in kernel variants (environment knobs read by mfgpu_create; tuning experiments,
+    profiles/r01_notes.md) compute the same operator: vmult and vmult_add against the oracle."""
+    monkeypatch.setenv(knob, "1")
+    mesh = mf.Mesh.uniform(dim, p, n)
+    od = oracle_desc_from_mesh(mesh, dtype=np.float64)
+    op = mf.Operator(mesh.desc, mesh)
+    rng = np.random.default_rng(17)
+    x, y0 = rng.standard_normal(mesh.n_dofs), rng.standard_normal(mesh.n_dofs)
+    assert rel(gpu_vmult(op, x), o.vmult(od, x)) <= 1e-12
+    assert rel(gpu_vmult(op, x, y0=y0), o.vmult_add(od, y0, x)) <= 1e-12
+
+
 @pytest.mark.parametrize("colored", [False, True])
 @pytest.mark.parametrize("dim,p,n", [(2, 2, 9), (3, 4, 3), (3, 2, 5)])
 def test_vmult_add_matches_oracle(dim, p, n, colored):
