@@ -181,6 +181,7 @@ def main():
         try:
             tr = json.load(open(tj))
             if (tr.get("workload") == f"p{p}_3d_n{n_glob}_{'f32' if args.float else 'f64'}" and world == 1
+                    and op.kernel_name() + "<" in tr.get("kernel", "")
                     and not args.adaptive and not args.colored and not args.batch_cells and not args.batch_dofs):
                 traffic = tr["hbm_bytes_per_launch"]
         except Exception:
@@ -208,7 +209,7 @@ def main():
                    "plan": stats, "finite": finite},
         "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                      "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
-                     "kernel": "apply_batches", "launches": launches,
+                     "kernel": op.kernel_name(), "launches": launches,
                      "avg_launch_us": 1e3 * k_ms / max(launches, 1),
                      "alg_bytes_per_launch": b_alg_loc / stats["n_launches"],
                      "kernel_ms_per_vmult": k_ms / max(n_v, 1)},

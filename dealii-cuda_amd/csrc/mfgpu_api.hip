@@ -29,6 +29,7 @@ struct mfgpu_handle {
   uint32_t *d_batch_cell_off = nullptr, *d_batch_dof_off = nullptr, *d_bdofs = nullptr;
   uint8_t *d_bflags = nullptr;
   uint16_t *d_lmap = nullptr;
+  uint16_t *d_lmapx = nullptr;
   void *d_coef = nullptr;
   uint32_t *d_cmask = nullptr, *d_orphans = nullptr;
   void *d_hnw = nullptr;
@@ -43,6 +44,7 @@ struct mfgpu_handle {
   int stagger = 0;        // see apply_batches
   bool plane = false;     // experimental plane-per-thread kernel (apply_planes)
   bool ls = false;        // loader / compute specialised cell loop (apply_batches_ls)
+  bool xk = false;        // 3D two-pass kernel for three workgroups per CU (apply_batches_x)
   bool wave = false;      // wave-granular cell phase (apply_batches<..., WAVE = true>)
   // profiling
   bool prof = false;
@@ -106,6 +108,14 @@ int create_typed(mfgpu_handle *h, const mfgpu_desc &d) {
   if ((rc = dev_upload(&h->d_bdofs, P.bdofs.data(), P.bdofs.size() * 4, acct))) return rc;
   if ((rc = dev_upload(&h->d_bflags, P.bflags.data(), P.bflags.size(), acct))) return rc;
   if ((rc = dev_upload(&h->d_lmap, P.lmap.data(), P.lmap.size() * 2, acct))) return rc;
+  if (h->xk) {
+    // x-pencil index runs (n contiguous entries of lmap) padded to whole 32-bit words
+    const size_t n = (size_t)P.n, np = (n + 1) & ~(size_t)1, runs = P.lmap.size() / n;
+    std::vector<uint16_t> lx(runs * np, 0);
+    for (size_t r = 0; r < runs; ++r)
+      for (size_t i = 0; i < n; ++i) lx[r * np + i] = P.lmap[r * n + i];
+    if ((rc = dev_upload(&h->d_lmapx, lx.data(), lx.size() * 2, acct))) return rc;
+  }
   if ((rc = dev_upload(&h->d_orphans, P.orphans.data(), P.orphans.size() * 4, acct))) return rc;
   if (h->twopass) {
     if ((rc = dev_upload(&h->d_batch_nint, P.batch_nint.data(), P.batch_nint.size() * 4, acct))) return rc;
@@ -178,6 +188,24 @@ int create_typed(mfgpu_handle *h, const mfgpu_desc &d) {
       if (atoi(e) > 0) h->max_grid = (uint32_t)atoi(e);
     return 0;
   }
+  if (h->xk) {
+    ApplyArgs<T> dummy{};
+    dummy.nb_max = P.max_batch_dofs;
+    int per_cu = 0, dev = 0;
+    hipDeviceProp_t prop;
+    HIP_TRY(x_launch<T>(P.n, dummy, nullptr, nullptr, h->hn, 0, nullptr, true, &h->lds, nullptr));
+    if (h->lds > 160 * 1024) {
+      set_error("batch needs more than 160 KiB of LDS; lower max_dofs_per_batch");
+      return MFGPU_EINVAL;
+    }
+    HIP_TRY(x_launch<T>(P.n, dummy, nullptr, nullptr, h->hn, 0, nullptr, true, &h->lds, &per_cu));
+    HIP_TRY(hipGetDevice(&dev));
+    HIP_TRY(hipGetDeviceProperties(&prop, dev));
+    h->max_grid = (uint32_t)(per_cu < 1 ? 1 : per_cu) * (uint32_t)prop.multiProcessorCount;
+    if (const char *e = getenv("MFGPU_GRID"))
+      if (atoi(e) > 0) h->max_grid = (uint32_t)atoi(e);
+    return 0;
+  }
   if (h->ls) {
     ApplyArgs<T> dummy{};
     dummy.nb_max = P.max_batch_dofs;
@@ -225,6 +253,7 @@ int vmult_typed(mfgpu_handle *h, void *dst, const void *src, hipStream_t st, int
   a.bdofs = h->d_bdofs;
   a.bflags = h->d_bflags;
   a.lmap = h->d_lmap;
+  a.lmapx = h->d_lmapx;
   a.coef = (const T *)h->d_coef;
   a.cmask = h->d_cmask;
   a.hn_weights = (const T *)h->d_hnw;
@@ -259,7 +288,10 @@ int vmult_typed(mfgpu_handle *h, void *dst, const void *src, hipStream_t st, int
       HIP_TRY(hipEventRecord(h->ev[h->ev_used], st));
     }
     a.batch_end = a.batch0 + nbat;
-    if (h->ls)
+    if (h->xk)
+      HIP_TRY(x_launch<T>(P.n, a, h->S.data(), h->Dt.data(), h->hn, nbat < h->max_grid ? nbat : h->max_grid, st,
+                          false, nullptr, nullptr));
+    else if (h->ls)
       HIP_TRY(ls_launch<T>(P.dim, P.n, a, h->S.data(), h->Dt.data(), h->hn, nbat < h->max_grid ? nbat : h->max_grid,
                            st, false, nullptr, nullptr));
     else if (h->plane)
@@ -328,6 +360,14 @@ int mfgpu_create(const mfgpu_desc *desc, mfgpu_handle **out) {
   // experimental loader / compute wave split (slower than apply_batches: profiles/r01_notes.md)
   if (const char *e = getenv("MFGPU_LS"))
     h->ls = atoi(e) != 0 && !h->wave && !h->plane && !(d.flags & MFGPU_COLORED_SCATTER);
+  // apply_batches_x: 3D two-pass default.  Its hanging-node variant spills at the 168-VGPR budget of
+  // three waves per SIMD, so meshes with hanging nodes keep apply_batches unless MFGPU_X=1 asks for it.
+  h->xk = d.dim == 3 && !h->wave && !h->plane && !h->ls && !(d.flags & MFGPU_COLORED_SCATTER);
+  {
+    const char *e = getenv("MFGPU_X");
+    if (e) h->xk = h->xk && atoi(e) != 0;
+    else if (hn) h->xk = false;
+  }
   int rc = build_plan(dplan, h->plan);
   if (rc) {
     delete h;
@@ -363,6 +403,7 @@ void mfgpu_destroy(mfgpu_handle *h) {
   hipFree(h->d_bdofs);
   hipFree(h->d_bflags);
   hipFree(h->d_lmap);
+  hipFree(h->d_lmapx);
   hipFree(h->d_coef);
   hipFree(h->d_cmask);
   hipFree(h->d_orphans);
@@ -425,6 +466,11 @@ int mfgpu_plan_stats(const mfgpu_handle *h, uint64_t s[8]) {
     s[7] = P.halo_off.back();
   }
   return 0;
+}
+
+const char *mfgpu_kernel_name(const mfgpu_handle *h) {
+  if (!h) return "";
+  return h->xk ? "apply_batches_x" : h->ls ? "apply_batches_ls" : h->plane ? "apply_planes" : "apply_batches";
 }
 
 int mfgpu_profile_enable(mfgpu_handle *h, int on) {

@@ -15,6 +15,7 @@ struct ApplyArgs {
   const uint32_t *bdofs;
   const uint8_t *bflags;
   const uint16_t *lmap;
+  const uint16_t *lmapx;  // apply_batches_x: x-pencil index runs padded to 32-bit words, or nullptr
   const T *coef;          // folded a*J0^2*JxW, plan cell order
   const uint32_t *cmask;  // plan cell order, or nullptr
   const T *hn_weights;    // [n*n] W[i*n+j] (device), or nullptr
@@ -55,6 +56,10 @@ hipError_t reduce_launch(T *dst, const T *src, const T *halo, const uint32_t *sd
 template <typename T>
 hipError_t plane_launch(int n, const ApplyArgs<T> &a, const double *S, const double *Dt, uint32_t grid,
                         hipStream_t st, bool configure_only, size_t *lds_out, int *occupancy);
+// 3D cell loop for three workgroups per CU (mfgpu_kernels_x.hip; two-pass mode)
+template <typename T>
+hipError_t x_launch(int n, const ApplyArgs<T> &a, const double *S, const double *Dt, bool hn, uint32_t grid,
+                    hipStream_t st, bool configure_only, size_t *lds_out, int *occupancy);
 // loader / compute specialised cell loop (mfgpu_kernels_ls.hip; two-pass mode)
 template <typename T>
 hipError_t ls_launch(int dim, int n, const ApplyArgs<T> &a, const double *S, const double *Dt, bool hn,

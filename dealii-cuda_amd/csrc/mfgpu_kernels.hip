@@ -64,8 +64,22 @@ apply_batches(const ApplyArgs<T> A, const Tables<T, n> tab) {
 
   // Workgroup loops over batches b, b + gridDim.x, ... of [batch0, batch_end) (grid = resident
   // workgroups).
-  const uint32_t bend = A.batch_end;
-  uint32_t b = A.batch0 + blockIdx.x;
+  // XCD-aware batch order (see apply_batches_x): block i runs on XCD i % 8; every XCD walks ONE contiguous
+  // range of batches so that the batches in flight on it are mesh neighbours and share src lines in its L2.
+  uint32_t b, bstride, bend;
+  {
+    const uint32_t nbt = A.batch_end - A.batch0, G = gridDim.x;
+    if ((G & 7u) == 0 && nbt >= G) {
+      const uint32_t xcd = blockIdx.x & 7u, slot = blockIdx.x >> 3;
+      b = A.batch0 + (uint32_t)((uint64_t)nbt * xcd / 8) + slot;
+      bend = A.batch0 + (uint32_t)((uint64_t)nbt * (xcd + 1) / 8);
+      bstride = G >> 3;
+    } else {
+      b = A.batch0 + blockIdx.x;
+      bend = A.batch_end;
+      bstride = G;
+    }
+  }
   if (b >= bend) return;
   // Stagger: all workgroups run batches of (nearly) identical length, so workgroups that start together
   // stay phase-aligned (the whole CU gathers, then the whole CU computes) and the memory and compute
@@ -93,8 +107,8 @@ apply_batches(const ApplyArgs<T> A, const Tables<T, n> tab) {
     for (int j = 0; j < kGU; ++j) {
       const int t = tid + j * kBlock;
       const int tc = t < nb_ ? t : nb_ - 1;
-      g_[j] = A.bdofs[d0_ + tc];
-      f_[j] = TWOPASS ? (uint8_t)0 : A.bflags[d0_ + tc];
+      g_[j] = __builtin_nontemporal_load(A.bdofs + d0_ + tc);  // read-once streams: keep the L2 for src
+      f_[j] = TWOPASS ? (uint8_t)0 : __builtin_nontemporal_load(A.bflags + d0_ + tc);
     }
   };
   auto load_src = [&](const uint32_t (&g_)[kGU], T (&sv_)[kGU]) {
@@ -122,8 +136,8 @@ apply_batches(const ApplyArgs<T> A, const Tables<T, n> tab) {
     for (int j = 0; j < PF; ++j) {
       const int i = gtid + j * GT;
       const int ic = i < cnt ? i : cnt - 1;  // clamped, branch-free
-      pc[j] = cg[ic];
-      pl[j] = lg[ic];
+      pc[j] = __builtin_nontemporal_load(cg + ic);
+      pl[j] = __builtin_nontemporal_load(lg + ic);
     }
   };
   auto stage = [&](int cnt) {
@@ -178,7 +192,7 @@ apply_batches(const ApplyArgs<T> A, const Tables<T, n> tab) {
       }
     }
     // next batch of this workgroup: meta data and dof list (the iteration's first global loads)
-    const uint32_t bn = b + gridDim.x;
+    const uint32_t bn = b + bstride;
     const bool has_nb = bn < bend;
     uint32_t c0n = c0, d0n = d0, hoffn = hoff;
     int nbn = nb, ncelln = ncell, nintn = nint;
@@ -234,7 +248,7 @@ apply_batches(const ApplyArgs<T> A, const Tables<T, n> tab) {
       else
         cell_pipeline<dim, n, T, HN, WgSync>(act, pa, pb, mask, any_mask, usrc, acc, Wc, Rc, cf, lm, Wl, tab, stage_next, A.dbg,
 #ifdef MFGPU_STAMPS
-                                             (A.stamps && k == 1) ? A.stamps + (size_t)(bend + b) * 16 : nullptr
+                                             (A.stamps && k == 1) ? A.stamps + (size_t)(A.batch_end + b) * 16 : nullptr
 #else
                                              nullptr
 #endif
@@ -268,9 +282,9 @@ apply_batches(const ApplyArgs<T> A, const Tables<T, n> tab) {
         for (int j = 0; j < kGU; ++j) {
           const int t = tid + j * kBlock;
           if (t < nint) {
-            if (!(G[j] >> 31)) A.dst[G[j]] = A.add ? old[j] + acc[t] : acc[t];
+            if (!(G[j] >> 31)) __builtin_nontemporal_store(A.add ? old[j] + acc[t] : acc[t], A.dst + G[j]);
           } else if (t < nb) {
-            halo[t - nint] = acc[t];  // constrained shared dofs: value ignored by reduce_shared
+            __builtin_nontemporal_store(acc[t], halo + (t - nint));  // constrained shared dofs: ignored by reduce_shared
           }
         }
       }

@@ -39,7 +39,7 @@ class Desc(C.Structure):
 # every symbol include/mfgpu.h declares (tests check that the library exports all of them)
 SYMBOLS = [
     "mfgpu_create", "mfgpu_vmult", "mfgpu_vmult_add", "mfgpu_n_dofs", "mfgpu_memory_consumption",
-    "mfgpu_destroy", "mfgpu_last_error", "mfgpu_plan_stats", "mfgpu_profile_enable", "mfgpu_profile_read",
+    "mfgpu_destroy", "mfgpu_last_error", "mfgpu_plan_stats", "mfgpu_kernel_name", "mfgpu_profile_enable", "mfgpu_profile_read",
     "mfgpu_plan_create", "mfgpu_plan_destroy", "mfgpu_plan_array_u32", "mfgpu_plan_lmap", "mfgpu_plan_bflags",
     "mfgpu_vec_alloc", "mfgpu_vec_free", "mfgpu_vec_fill", "mfgpu_vec_from_host", "mfgpu_vec_to_host",
     "mfgpu_device_synchronize", "mfgpu_mesh_create_uniform", "mfgpu_mesh_create_adaptive", "mfgpu_mesh_create_from_leaves",
@@ -68,6 +68,8 @@ def lib():
         L.mfgpu_destroy.argtypes = [C.c_void_p]
         L.mfgpu_destroy.restype = None
         L.mfgpu_plan_stats.argtypes = [C.c_void_p, C.POINTER(C.c_uint64)]
+        L.mfgpu_kernel_name.argtypes = [C.c_void_p]
+        L.mfgpu_kernel_name.restype = C.c_char_p
         L.mfgpu_profile_enable.argtypes = [C.c_void_p, C.c_int]
         L.mfgpu_profile_read.argtypes = [C.c_void_p, C.POINTER(C.c_double), C.POINTER(C.c_uint64)]
         L.mfgpu_plan_create.argtypes = [C.POINTER(Desc), C.POINTER(C.c_void_p)]
@@ -355,6 +357,9 @@ class Operator:
         keys = ["n_batches", "n_launches", "batch_dofs", "max_batch_dofs", "max_batch_cells", "n_orphans",
                 "first_touch_or_shared_dofs", "rmw_adds_or_halo_slots"]
         return dict(zip(keys, [int(v) for v in s]))
+
+    def kernel_name(self):
+        return lib().mfgpu_kernel_name(self._h).decode()
 
     def profile_enable(self, on=True):
         _check(lib().mfgpu_profile_enable(self._h, int(on)))

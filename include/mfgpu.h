@@ -118,6 +118,10 @@ const char *mfgpu_last_error(void);
  * [6]=first-touch stores (coloured) / shared dofs (two-pass) [7]=RMW adds (coloured) / halo slots (two-pass) */
 int mfgpu_plan_stats(const mfgpu_handle *h, uint64_t stats[8]);
 
+/* Name of the cell-loop kernel this operator launches ("apply_batches_x", "apply_batches", ...): the
+ * kernel the roofline figures of bench.py and the rocprofv3 summaries under profiles/ refer to.      */
+const char *mfgpu_kernel_name(const mfgpu_handle *h);
+
 /* Average device time of the cell-loop kernels of the most recent mfgpu_vmult* calls, measured
  * with hipEvents on the launch stream when profiling is enabled (bench.py roofline leg).       */
 int mfgpu_profile_enable(mfgpu_handle *h, int on);

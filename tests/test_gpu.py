@@ -56,15 +56,21 @@ def test_vmult_matches_oracle(dim, p, n, nt, colored):
     assert rel(y, o.vmult(od, x.astype(mf.np_dtype(nt)).astype(np.float64))) <= TOL[nt]
 
 
-@pytest.mark.parametrize("knob", ["MFGPU_LS", "MFGPU_WAVE", "MFGPU_PLANE"])
+KNOBS = [("MFGPU_X", "0", "apply_batches"), ("MFGPU_LS", "1", "apply_batches_ls"),
+         ("MFGPU_WAVE", "1", "apply_batches"), ("MFGPU_PLANE", "1", "apply_planes")]
+
+
+@pytest.mark.parametrize("knob,value,kernel", KNOBS, ids=[k[0] + "=" + k[1] for k in KNOBS])
 @pytest.mark.parametrize("dim,p,n", [(3, 4, 7), (3, 2, 9), (2, 3, 12)])
-def test_experimental_kernel_variants_match_oracle(knob, dim, p, n, monkeypatch):
-    """The opt-in kernel variants (environment knobs read by mfgpu_create; tuning experiments,
+def test_kernel_variants_match_oracle(knob, value, kernel, dim, p, n, monkeypatch):
+    """The non-default kernel variants (environment knobs read by mfgpu_create; tuning experiments,
     profiles/r01_notes.md) compute the same operator: vmult and vmult_add against the oracle."""
-    monkeypatch.setenv(knob, "1")
+    monkeypatch.setenv(knob, value)
     mesh = mf.Mesh.uniform(dim, p, n)
     od = oracle_desc_from_mesh(mesh, dtype=np.float64)
     op = mf.Operator(mesh.desc, mesh)
+    if dim == 3 and knob != "MFGPU_LS":
+        assert op.kernel_name() == kernel
     rng = np.random.default_rng(17)
     x, y0 = rng.standard_normal(mesh.n_dofs), rng.standard_normal(mesh.n_dofs)
     assert rel(gpu_vmult(op, x), o.vmult(od, x)) <= 1e-12
@@ -227,11 +233,16 @@ def _all_masks(dim):
 
 
 @pytest.mark.parametrize("dim,p,n", [(2, 1, 8), (2, 2, 8), (2, 4, 8), (3, 1, 5), (3, 2, 4), (3, 3, 4), (3, 4, 4), (3, 5, 3)])
-@pytest.mark.parametrize("colored", [False, True])
-def test_hanging_node_stages_synthetic_masks(dim, p, n, colored):
+@pytest.mark.parametrize("colored", [False, True, "x"])
+def test_hanging_node_stages_synthetic_masks(dim, p, n, colored, monkeypatch):
     """in-kernel resolve_hanging_nodes (NOTRANSPOSE before evaluate, TRANSPOSE after integrate,
     fee_gpu.cuh:333-335,349-351) against the oracle's emulation for every mask type.  The masks are
     assigned to cells of a conforming mesh: algebraically A = sum_cells P^T C^T K C P either way."""
+    if colored == "x":  # two-pass mode, hanging-node variant of apply_batches_x (3D)
+        if dim != 3:
+            pytest.skip("apply_batches_x is a 3D kernel")
+        monkeypatch.setenv("MFGPU_X", "1")
+        colored = False
     od = o.uniform_mesh_desc(dim, p, n)
     masks = _all_masks(dim)
     rng = np.random.default_rng(5)
@@ -264,6 +275,21 @@ def test_adaptive_mesh_with_hanging_nodes(dim, p, nref, colored):
     x = rng.standard_normal(mesh.n_dofs)
     assert rel(gpu_vmult(op, x), o.vmult(od, x)) <= 1e-12
     y0 = rng.standard_normal(mesh.n_dofs)
+    assert rel(gpu_vmult(op, x, y0=y0), o.vmult_add(od, y0, x)) <= 1e-12
+
+
+@pytest.mark.parametrize("p,nref", [(4, 4), (2, 4), (3, 5)])
+def test_adaptive_mesh_x_kernel_hanging_node_variant(p, nref, monkeypatch):
+    """apply_batches_x is the 3D default only without hanging nodes (its HN variant spills registers);
+    MFGPU_X=1 selects it for an adaptive mesh as well: same operator."""
+    monkeypatch.setenv("MFGPU_X", "1")
+    mesh = mf.Mesh.adaptive(3, p, nref)
+    od = oracle_desc_from_mesh(mesh, dtype=np.float64)
+    op = mf.Operator(mesh.desc, mesh)
+    assert op.kernel_name() == "apply_batches_x"
+    rng = np.random.default_rng(5)
+    x, y0 = rng.standard_normal(mesh.n_dofs), rng.standard_normal(mesh.n_dofs)
+    assert rel(gpu_vmult(op, x), o.vmult(od, x)) <= 1e-12
     assert rel(gpu_vmult(op, x, y0=y0), o.vmult_add(od, y0, x)) <= 1e-12
 
 

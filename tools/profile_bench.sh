@@ -13,4 +13,6 @@ timeout -k 5 300 rocprofv3 --kernel-trace --stats --output-format csv -d $O/kt -
 timeout -k 5 300 rocprofv3 --pmc FETCH_SIZE --output-format csv -d $O/fetch -- $B > $O/fetch.log 2>&1; echo "fetch rc=$?"
 timeout -k 5 300 rocprofv3 --pmc WRITE_SIZE --output-format csv -d $O/write -- $B > $O/write.log 2>&1; echo "write rc=$?"
 timeout -k 5 300 rocprofv3 --pmc TCC_HIT_sum TCC_MISS_sum --output-format csv -d $O/l2 -- $B > $O/l2.log 2>&1; echo "l2 rc=$?"
+# cross-check of the calibrated read side: the L2's fabric read requests by size (32 / 64 / 128 B)
+timeout -k 5 300 rocprofv3 --pmc TCC_EA0_RDREQ_sum TCC_EA0_RDREQ_32B_sum TCC_EA0_RDREQ_64B_sum TCC_EA0_RDREQ_128B_sum --output-format csv -d $O/rdreq -- $B > $O/rdreq.log 2>&1; echo "rdreq rc=$?"
 python3 $R/tools/profile_summary.py $O $R/gpurun_out/${TAG}_summary

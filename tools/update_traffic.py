@@ -10,10 +10,11 @@ t = json.load(open(summary))
 name = [k for k in t["kernels"] if sub in k][0]
 v = t["kernels"][name]
 out = {"workload": workload, "kernel": name, "hbm_bytes_per_launch": v["hbm_bytes"],
-       "read_bytes_calibrated": v["read_bytes_calibrated"], "write_bytes": v["WRITE_SIZE_bytes"],
-       "fetch_calibration": t["fetch_calibration"],
-       "source": "profiles/r01_bench_pmc_traffic.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate "
-                 "passes, tools/profile_bench.sh)"}
+       "read_bytes": v["hbm_bytes"] - v["WRITE_SIZE_bytes"], "write_bytes": v["WRITE_SIZE_bytes"],
+       "FETCH_SIZE_bytes_raw": v["FETCH_SIZE_bytes_raw"], "rdreq": v.get("rdreq"),
+       "source": "profiles/r01_bench_pmc_traffic.json (rocprofv3 --pmc, separate passes for FETCH_SIZE, WRITE_SIZE "
+                 "and TCC_EA0_RDREQ by size; reads = 128-B requests x 128 = 2 x FETCH_SIZE on gfx950; "
+                 "tools/profile_bench.sh, tools/profile_summary.py)"}
 root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 json.dump(out, open(os.path.join(root, "profiles", "traffic_latest.json"), "w"), indent=1)
 print(name, out["hbm_bytes_per_launch"])
