@@ -64,21 +64,16 @@ apply_batches(const ApplyArgs<T> A, const Tables<T, n> tab) {
 
   // Workgroup loops over batches b, b + gridDim.x, ... of [batch0, batch_end) (grid = resident
   // workgroups).
-  // XCD-aware batch order (see apply_batches_x): block i runs on XCD i % 8; every XCD walks ONE contiguous
-  // range of batches so that the batches in flight on it are mesh neighbours and share src lines in its L2.
-  uint32_t b, bstride, bend;
+  // XCD-aware batch order (see apply_batches_x): block i runs on XCD i % 8; in every round of gridDim.x
+  // batches XCD x takes the x-th contiguous eighth, so the batches in flight on it are mesh neighbours
+  // and all XCDs advance through the batch list together: hanging-node batches, which cost more, cluster
+  // in space, and one contiguous range per XCD (apply_batches_x) would leave that XCD behind.
+  const uint32_t bend = A.batch_end, bstride = gridDim.x;
+  uint32_t b;
   {
-    const uint32_t nbt = A.batch_end - A.batch0, G = gridDim.x;
-    if ((G & 7u) == 0 && nbt >= G) {
-      const uint32_t xcd = blockIdx.x & 7u, slot = blockIdx.x >> 3;
-      b = A.batch0 + (uint32_t)((uint64_t)nbt * xcd / 8) + slot;
-      bend = A.batch0 + (uint32_t)((uint64_t)nbt * (xcd + 1) / 8);
-      bstride = G >> 3;
-    } else {
-      b = A.batch0 + blockIdx.x;
-      bend = A.batch_end;
-      bstride = G;
-    }
+    const uint32_t G = gridDim.x;
+    // block i -> position (i % 8) * G/8 + i / 8 of the round: XCD x takes the x-th contiguous eighth
+    b = A.batch0 + (((G & 7u) == 0) ? (blockIdx.x & 7u) * (G >> 3) + (blockIdx.x >> 3) : blockIdx.x);
   }
   if (b >= bend) return;
   // Stagger: all workgroups run batches of (nearly) identical length, so workgroups that start together
@@ -282,9 +277,9 @@ apply_batches(const ApplyArgs<T> A, const Tables<T, n> tab) {
         for (int j = 0; j < kGU; ++j) {
           const int t = tid + j * kBlock;
           if (t < nint) {
-            if (!(G[j] >> 31)) __builtin_nontemporal_store(A.add ? old[j] + acc[t] : acc[t], A.dst + G[j]);
+            if (!(G[j] >> 31)) A.dst[G[j]] = A.add ? old[j] + acc[t] : acc[t];
           } else if (t < nb) {
-            __builtin_nontemporal_store(acc[t], halo + (t - nint));  // constrained shared dofs: ignored by reduce_shared
+            halo[t - nint] = acc[t];  // constrained shared dofs: value ignored by reduce_shared
           }
         }
       }

@@ -23,6 +23,14 @@
 
 namespace mfgpu {
 
+#ifdef MFGPU_PLAIN_STREAMS
+template <typename U>
+__device__ __forceinline__ U stream_load(const U *p) { return *p; }
+#else
+template <typename U>
+__device__ __forceinline__ U stream_load(const U *p) { return __builtin_nontemporal_load(p); }
+#endif
+
 template <int n>
 __device__ __forceinline__ int ix_at(const uint32_t (&w)[(n + 1) / 2], int i) {
   return (int)((w[i >> 1] >> (16 * (i & 1))) & 0xffffu);
@@ -189,22 +197,26 @@ apply_batches_x(const ApplyArgs<T> A, const Tables<T, n> tab) {
   const int tid = threadIdx.x;
   // Persistent workgroups; XCD-aware batch order.  Workgroups are dispatched round-robin over the 8 XCDs
   // (block i runs on XCD i % 8) and every XCD has its own L2.  Consecutive batches are neighbours in the
-  // mesh: they share halo dofs and the 128-byte lines their 13-dof runs of src straddle.  Each XCD
-  // therefore gets ONE contiguous range of batches, walked by its workgroups in steps of gridDim/8, so
-  // that the batches in flight on an XCD are neighbours (x and y) and share those lines in its L2.
+  // mesh (two-pass plans keep the spatial creation order): they share halo dofs and the 128-byte lines
+  // their 13-dof runs of src straddle.  Each XCD therefore gets ONE contiguous range of batches, walked by
+  // its workgroups in steps of gridDim/8, so that the batches in flight on one XCD are neighbours and hit
+  // in its L2: fabric reads 500 -> 404 MB per launch together with the spatial plan order.  (Handing each
+  // XCD the x-th eighth of every ROUND of gridDim batches instead balances better when batch cost varies
+  // -- apply_batches does that for hanging-node meshes -- but leaves three XCDs idle in the partial last
+  // round of a uniform mesh: 4 % slower here.)
   // (A contiguous run of batches per workgroup instead -- the same lines re-requested one batch later --
   // fetched 5 % more and was 4 % slower: the L2 turns over in less than one batch time.)
-  // The read-once streams (dof lists, index runs, coefficients) and the result stores are non-temporal
-  // so that they do not push src lines out of the L2 (-2 % time, -2.5 % fabric reads).
+  // The read-once streams (dof lists, index runs, coefficients) are loaded non-temporally so that they
+  // do not push src lines out of the L2; the result stores are plain: neighbouring batches write
+  // adjacent runs of dst at about the same time and the L2 merges them into full lines (non-temporal
+  // stores: +24 % written bytes, +3 % time).
   uint32_t b, bstride, bend;
   {
     const uint32_t nbt = A.batch_end - A.batch0, G = gridDim.x;
     if ((G & 7u) == 0 && nbt >= G) {
       const uint32_t xcd = blockIdx.x & 7u, slot = blockIdx.x >> 3;
-      const uint32_t lo = A.batch0 + (uint32_t)((uint64_t)nbt * xcd / 8);
-      const uint32_t hi = A.batch0 + (uint32_t)((uint64_t)nbt * (xcd + 1) / 8);
-      b = lo + slot;
-      bend = hi;
+      b = A.batch0 + (uint32_t)((uint64_t)nbt * xcd / 8) + slot;
+      bend = A.batch0 + (uint32_t)((uint64_t)nbt * (xcd + 1) / 8);
       bstride = G >> 3;
     } else {
       b = A.batch0 + blockIdx.x;
@@ -247,7 +259,7 @@ apply_batches_x(const ApplyArgs<T> A, const Tables<T, n> tab) {
 #pragma unroll
     for (int j = 0; j < kGU; ++j) {
       const int t = l + j * kBlock;
-      g_[j] = __builtin_nontemporal_load(bd + (t < nb_ ? t : nb_ - 1));
+      g_[j] = stream_load(bd + (t < nb_ ? t : nb_ - 1));
     }
   };
   auto load_src = [&](const uint32_t (&g_)[kGU], T (&sv_)[kGU]) {
@@ -263,7 +275,7 @@ apply_batches_x(const ApplyArgs<T> A, const Tables<T, n> tab) {
       cell = cell < ncell_ ? cell : ncell_ - 1;
       const uint32_t *p = lx + ((size_t)(c0_ + cell) * P + (lane_on ? pen : 0)) * NW;
 #pragma unroll
-      for (int q = 0; q < NW; ++q) ix_[k][q] = __builtin_nontemporal_load(p + q);
+      for (int q = 0; q < NW; ++q) ix_[k][q] = stream_load(p + q);
     }
   };
   T pc[PF];
@@ -273,7 +285,7 @@ apply_batches_x(const ApplyArgs<T> A, const Tables<T, n> tab) {
 #pragma unroll
     for (int j = 0; j < PF; ++j) {
       const int i = l + j * kBlock;
-      pc[j] = __builtin_nontemporal_load(cg + (i < cnt ? i : cnt - 1));
+      pc[j] = stream_load(cg + (i < cnt ? i : cnt - 1));
     }
   };
   auto stage = [&](int cnt) {
@@ -405,9 +417,9 @@ apply_batches_x(const ApplyArgs<T> A, const Tables<T, n> tab) {
 #pragma unroll
       for (int j = 0; j < kGU; ++j) {
         if (l < nint - j * kBlock) {
-          if (!(G[j] >> 31)) __builtin_nontemporal_store(A.add ? old[j] + ul[j * kBlock] : ul[j * kBlock], A.dst + G[j]);
+          if (!(G[j] >> 31)) A.dst[G[j]] = A.add ? old[j] + ul[j * kBlock] : ul[j * kBlock];
         } else if (l < nb - j * kBlock) {
-          __builtin_nontemporal_store(ul[j * kBlock], hl + j * kBlock);  // constrained shared dofs: ignored by reduce_shared
+          hl[j * kBlock] = ul[j * kBlock];  // constrained shared dofs: value ignored by reduce_shared
         }
       }
     }

@@ -248,15 +248,23 @@ int build_plan(const mfgpu_desc &d, Plan &P) {
     ncolors = std::max(ncolors, c + 1);
     for (uint32_t g : bd[b]) dof_colors[g] |= (1ull << c);
   }
-  // execution order: colour-major, stable
+  // execution order.  Coloured scatter: colour-major, stable (one launch per colour).  Two-pass scatter
+  // has no inter-batch dependency: the batches keep their creation order, which follows the caller's
+  // cell order and is therefore spatially coherent -- batches that run at the same time on one XCD are
+  // mesh neighbours and share the 128-byte lines of src that their dof runs straddle (a colour-major
+  // order puts every neighbour into a different colour, i.e. as far apart in time as possible).
+  const bool colored = (d.flags & MFGPU_COLORED_SCATTER) != 0;
   std::vector<uint32_t> order(nb);
   std::iota(order.begin(), order.end(), 0u);
-  std::stable_sort(order.begin(), order.end(),
-                   [&](uint32_t a, uint32_t b2) { return bcolor[a] < bcolor[b2]; });
-
-  P.color_batch_off.assign(ncolors + 1, 0);
-  for (uint32_t b = 0; b < nb; ++b) P.color_batch_off[bcolor[b] + 1]++;
-  for (uint32_t c = 0; c < ncolors; ++c) P.color_batch_off[c + 1] += P.color_batch_off[c];
+  if (colored) {
+    std::stable_sort(order.begin(), order.end(),
+                     [&](uint32_t a, uint32_t b2) { return bcolor[a] < bcolor[b2]; });
+    P.color_batch_off.assign(ncolors + 1, 0);
+    for (uint32_t b = 0; b < nb; ++b) P.color_batch_off[bcolor[b] + 1]++;
+    for (uint32_t c = 0; c < ncolors; ++c) P.color_batch_off[c + 1] += P.color_batch_off[c];
+  } else {
+    P.color_batch_off.assign({0u, nb});
+  }
 
   // ---- emit arrays in execution order
   P.cell_order.clear();

@@ -67,7 +67,7 @@ def test_c1_sizes():
     assert (m.n_cells, m.n_dofs, m.desc.n_constrained) == (1024, 4225, 256)
 
 
-def _plan_invariants(od, plan):
+def _plan_invariants(od, plan, colored=False):
     nd = od.nd
     bco, bdo, cbo = plan.batch_cell_off, plan.batch_dof_off, plan.color_batch_off
     order, bdofs, bflags, lmap = plan.cell_order, plan.bdofs, plan.bflags, plan.lmap
@@ -75,6 +75,8 @@ def _plan_invariants(od, plan):
     # every cell exactly once
     assert sorted(order.tolist()) == list(range(od.n_cells))
     assert bco[0] == 0 and bco[-1] == od.n_cells and cbo[0] == 0 and cbo[-1] == nb
+    if not colored:  # two-pass plans keep the spatial creation order: one launch over all batches
+        assert len(cbo) == 2
     con = np.zeros(od.n_dofs, bool)
     con[od.constrained] = True
     touched = np.zeros(od.n_dofs, bool)
@@ -97,13 +99,15 @@ def _plan_invariants(od, plan):
             assert len(np.unique(g)) == len(g)
             assert (ntouch[g[:ni]] == 1).all() and (ntouch[g[ni:]] >= 2).all()
             assert plan.halo_off[b + 1] - plan.halo_off[b] == len(g) - ni
-            assert not seen[g].any()                                 # colour is conflict-free
+            assert not (colored and seen[g].any())                   # colour is conflict-free
             seen[g] = True
             np.testing.assert_array_equal((f & 1).astype(bool), con[g])
             np.testing.assert_array_equal(plan.bdofs_constrained[bdo[b]:bdo[b + 1]], con[g])
             np.testing.assert_array_equal((f & 2).astype(bool), touched[g])  # first toucher stores
             cells = np.arange(bco[b], bco[b + 1])
             np.testing.assert_array_equal(g[lmap[cells]], od.loc2glob[order[cells]])
+            if not colored:
+                touched[g] = True
         touched |= seen
     orph = plan.orphans
     np.testing.assert_array_equal(np.sort(orph & 0x7fffffff), np.nonzero(~touched)[0])
@@ -117,17 +121,18 @@ def _plan_invariants(od, plan):
 ])
 def test_plan_invariants_and_dataflow(dim, p, n, kw):
     od = o.uniform_mesh_desc(dim, p, n)
-    desc, keep = desc_from_oracle(od, **kw)
-    plan = mf.Plan(desc, keep)
-    _plan_invariants(od, plan)
     rng = np.random.default_rng(0)
     x, y0 = rng.standard_normal(od.n_dofs), rng.standard_normal(od.n_dofs)
-    ref = o.vmult(od, x)
-    for tp in (False, True):
-        np.testing.assert_allclose(emulate_plan_vmult(od, plan, x, twopass=tp), ref, rtol=0, atol=1e-12 * np.abs(ref).max())
-    ref = o.vmult_add(od, y0, x)
-    for tp in (False, True):
-        np.testing.assert_allclose(emulate_plan_vmult(od, plan, x, y0, twopass=tp), ref, rtol=0, atol=1e-12 * np.abs(ref).max())
+    for colored in (False, True):  # two-pass plan (spatial batch order) / coloured plan (colour-major order)
+        desc, keep = desc_from_oracle(od, colored=colored, **kw)
+        plan = mf.Plan(desc, keep)
+        _plan_invariants(od, plan, colored)
+        ref = o.vmult(od, x)
+        for tp in (False, True):  # the sequential emulation of either data flow is valid for both plans
+            np.testing.assert_allclose(emulate_plan_vmult(od, plan, x, twopass=tp), ref, rtol=0, atol=1e-12 * np.abs(ref).max())
+        ref = o.vmult_add(od, y0, x)
+        for tp in (False, True):
+            np.testing.assert_allclose(emulate_plan_vmult(od, plan, x, y0, twopass=tp), ref, rtol=0, atol=1e-12 * np.abs(ref).max())
 
 
 def test_plan_orphans_and_ragged_mesh():
@@ -136,14 +141,15 @@ def test_plan_orphans_and_ragged_mesh():
     keep_cells = np.array([0, 1, 2, 5, 10, 15])  # holes -> orphans, disconnected pieces
     od2 = o.Desc(2, 2, od.n_dofs, od.loc2glob[keep_cells], od.JxW[keep_cells], od.inv_jac[keep_cells],
                  od.coefficient[keep_cells], od.constrained)
-    desc, keep = desc_from_oracle(od2, max_cells_per_batch=3)
-    plan = mf.Plan(desc, keep)
-    _plan_invariants(od2, plan)
-    assert len(plan.orphans) > 0
     x = np.random.default_rng(1).standard_normal(od.n_dofs)
     ref = o.vmult(od2, x)
-    for tp in (False, True):
-        np.testing.assert_allclose(emulate_plan_vmult(od2, plan, x, twopass=tp), ref, atol=1e-12 * np.abs(ref).max())
+    for colored in (False, True):
+        desc, keep = desc_from_oracle(od2, max_cells_per_batch=3, colored=colored)
+        plan = mf.Plan(desc, keep)
+        _plan_invariants(od2, plan, colored)
+        assert len(plan.orphans) > 0
+        for tp in (False, True):
+            np.testing.assert_allclose(emulate_plan_vmult(od2, plan, x, twopass=tp), ref, atol=1e-12 * np.abs(ref).max())
 
 
 def test_batching_quality_structured():
@@ -155,7 +161,13 @@ def test_batching_quality_structured():
     assert nb == 27, nb
     assert np.diff(plan.batch_dof_off).max() == 13 ** 3
     assert plan.batch_nint.min() == 11 ** 3  # the one batch in the middle of the 3x3x3 arrangement
-    assert len(plan.color_batch_off) - 1 == 8
+    # two-pass plans run the batches in spatial (creation) order: consecutive batches are x-neighbours,
+    # which is what lets concurrently running workgroups share src lines in one XCD's L2
+    first = plan.cell_order[plan.batch_cell_off[:-1]]
+    np.testing.assert_array_equal(first, [3 * bx + 9 * (3 * by) + 81 * (3 * bz)
+                                          for bz in range(3) for by in range(3) for bx in range(3)])
+    desc, keep = desc_from_oracle(od, max_cells_per_batch=27, colored=True)
+    assert len(mf.Plan(desc, keep).color_batch_off) - 1 == 8
 
 
 def test_slab_meshes_tile_the_global_mesh():
