@@ -25,6 +25,7 @@ struct mfgpu_handle {
   int dim = 0, n = 0, nd = 0, number_type = MFGPU_F64;
   bool hn = false;
   std::vector<double> S, Dt;
+  std::vector<double> sv, sg;  // the caller's 1D tables (diagonal)
   // device arrays
   uint32_t *d_batch_cell_off = nullptr, *d_batch_dof_off = nullptr, *d_bdofs = nullptr;
   uint8_t *d_bflags = nullptr;
@@ -33,6 +34,9 @@ struct mfgpu_handle {
   void *d_coef = nullptr;
   uint32_t *d_cmask = nullptr, *d_orphans = nullptr;
   void *d_hnw = nullptr;
+  uint32_t *d_constrained = nullptr;  // constrained dof list (set_constrained_values)
+  uint32_t n_constrained = 0;
+  void *d_tab2 = nullptr;  // [2][n*n] squared 1D tables of the diagonal kernel, built on first use
   // two-pass mode
   bool twopass = true;
   uint32_t *d_batch_nint = nullptr, *d_halo_off = nullptr, *d_sdofs = nullptr, *d_s_off = nullptr,
@@ -315,6 +319,67 @@ int vmult_typed(mfgpu_handle *h, void *dst, const void *src, hipStream_t st, int
 
 }  // namespace
 
+// ---- diagonal, set_constrained_values
+namespace {
+template <typename T>
+int inverse_diagonal_typed(mfgpu_handle *h, void *diag, hipStream_t st) {
+  const Plan &P = h->plan;
+  if (!h->d_tab2) {  // squared 1D tables [S.^2 | G.^2], T[2][n*n]
+    const int nn = h->n * h->n;
+    std::vector<T> t2(2 * (size_t)nn);
+    for (int i = 0; i < nn; ++i) {
+      t2[i] = (T)(h->sv[i] * h->sv[i]);
+      t2[nn + i] = (T)(h->sg[i] * h->sg[i]);
+    }
+    int rc = dev_upload(&h->d_tab2, t2.data(), t2.size() * sizeof(T), h->device_bytes);
+    if (rc) return rc;
+  }
+  // inv_diag.reinit(m()): zero  (laplace_operator_gpu.h:407)
+  HIP_TRY(fill_launch<T>((T *)diag, P.n_dofs, T(0), st));
+  // data.cell_loop(inv_diag, diag_loc_op)  (:409-410)
+  HIP_TRY(diag_launch<T>(P.dim, P.n, (T *)diag, (uint32_t)(P.batch_cell_off.size() - 1), h->d_batch_cell_off,
+                         h->d_batch_dof_off, h->d_bdofs, h->d_lmap, (const T *)h->d_coef, h->d_cmask,
+                         (const T *)h->d_hnw, (const T *)h->d_tab2, st));
+  // constraint_handler.set_constrained_values(inv_diag, 1.0)  (:412)
+  HIP_TRY(set_values_launch<T>((T *)diag, h->d_constrained, h->n_constrained, T(1), st));
+  // inv_diag.invert()  (:414)
+  HIP_TRY(vec_map_launch<T>(4, (T *)diag, nullptr, T(0), T(0), P.n_dofs, st));
+  return 0;
+}
+}  // namespace
+
+
+// ---- GpuVector BLAS-1 and reductions
+namespace {
+int vec_map(int op, void *v, const void *w, double s, double a, size_t n, int nt, void *stream) {
+  if ((!v && n) || (!w && n && op <= 3)) {
+    set_error("null vector");
+    return MFGPU_EINVAL;
+  }
+  if (nt == MFGPU_F32)
+    HIP_TRY(vec_map_launch<float>(op, (float *)v, (const float *)w, (float)s, (float)a, n, (hipStream_t)stream));
+  else if (nt == MFGPU_F64)
+    HIP_TRY(vec_map_launch<double>(op, (double *)v, (const double *)w, s, a, n, (hipStream_t)stream));
+  else
+    return MFGPU_EINVAL;
+  return 0;
+}
+int vec_reduce(int op, void *v, const void *x, const void *w, double a, size_t n, int nt, void *stream, double *out) {
+  if (!out || (n && (!v || (op != 2 && !w) || (op == 1 && !x)))) {
+    set_error("null argument");
+    return MFGPU_EINVAL;
+  }
+  if (nt == MFGPU_F32)
+    HIP_TRY(vec_reduce_launch<float>(op, (float *)v, (const float *)x, (const float *)w, (float)a, n, (hipStream_t)stream, out));
+  else if (nt == MFGPU_F64)
+    HIP_TRY(vec_reduce_launch<double>(op, (double *)v, (const double *)x, (const double *)w, a, n, (hipStream_t)stream, out));
+  else
+    return MFGPU_EINVAL;
+  return 0;
+}
+}  // namespace
+
+
 extern "C" {
 
 int mfgpu_create(const mfgpu_desc *desc, mfgpu_handle **out) {
@@ -385,9 +450,15 @@ int mfgpu_create(const mfgpu_desc *desc, mfgpu_handle **out) {
     sv[i] = d.number_type == MFGPU_F64 ? ((const double *)d.shape_values)[i] : ((const float *)d.shape_values)[i];
     sg[i] = d.number_type == MFGPU_F64 ? ((const double *)d.shape_gradients)[i] : ((const float *)d.shape_gradients)[i];
   }
+  h->sv = sv;
+  h->sg = sg;
   rc = derive_tables(h->n, sv.data(), sg.data(), h->S, h->Dt);
   if (!rc) rc = check_symmetrize(h->n, h->S, h->Dt);
   if (!rc) rc = d.number_type == MFGPU_F64 ? create_typed<double>(h, d) : create_typed<float>(h, d);
+  if (!rc && d.n_constrained) {
+    h->n_constrained = d.n_constrained;
+    rc = dev_upload(&h->d_constrained, d.constrained_dofs, (size_t)d.n_constrained * 4, h->device_bytes);
+  }
   if (rc) {
     mfgpu_destroy(h);
     return rc;
@@ -404,6 +475,8 @@ void mfgpu_destroy(mfgpu_handle *h) {
   hipFree(h->d_bflags);
   hipFree(h->d_lmap);
   hipFree(h->d_lmapx);
+  hipFree(h->d_constrained);
+  hipFree(h->d_tab2);
   hipFree(h->d_coef);
   hipFree(h->d_cmask);
   hipFree(h->d_orphans);
@@ -517,6 +590,65 @@ int mfgpu_debug_stamps(mfgpu_handle *h, unsigned long long *out, size_t n_batche
 // ---- GpuVector pieces -----------------------------------------------------------------------
 
 static size_t esize(int nt) { return nt == MFGPU_F32 ? 4 : 8; }
+
+// ---- diagonal, set_constrained_values
+int mfgpu_compute_inverse_diagonal(mfgpu_handle *h, void *inv_diag, void *stream) {
+  if (!h || !inv_diag) {
+    set_error("null argument");
+    return MFGPU_EINVAL;
+  }
+  return h->number_type == MFGPU_F64 ? inverse_diagonal_typed<double>(h, inv_diag, (hipStream_t)stream)
+                                     : inverse_diagonal_typed<float>(h, inv_diag, (hipStream_t)stream);
+}
+
+int mfgpu_set_constrained_values(mfgpu_handle *h, void *vec, double value, void *stream) {
+  if (!h || !vec) {
+    set_error("null argument");
+    return MFGPU_EINVAL;
+  }
+  if (h->number_type == MFGPU_F64)
+    HIP_TRY(set_values_launch<double>((double *)vec, h->d_constrained, h->n_constrained, value, (hipStream_t)stream));
+  else
+    HIP_TRY(set_values_launch<float>((float *)vec, h->d_constrained, h->n_constrained, (float)value, (hipStream_t)stream));
+  return 0;
+}
+
+// ---- GpuVector BLAS-1 and reductions
+int mfgpu_vec_sadd(void *v, double s, double a, const void *w, size_t n, int nt, void *stream) {
+  return vec_map(0, v, w, s, a, n, nt, stream);
+}
+int mfgpu_vec_equ(void *v, double a, const void *w, size_t n, int nt, void *stream) {
+  return vec_map(1, v, w, 0.0, a, n, nt, stream);
+}
+int mfgpu_vec_scale(void *v, const void *w, size_t n, int nt, void *stream) {
+  return vec_map(2, v, w, 0.0, 0.0, n, nt, stream);
+}
+int mfgpu_vec_divide(void *v, const void *w, size_t n, int nt, void *stream) {
+  return vec_map(3, v, w, 0.0, 0.0, n, nt, stream);
+}
+int mfgpu_vec_invert(void *v, size_t n, int nt, void *stream) { return vec_map(4, v, nullptr, 0.0, 0.0, n, nt, stream); }
+int mfgpu_vec_mul(void *v, double a, size_t n, int nt, void *stream) {
+  return vec_map(5, v, nullptr, 0.0, a, n, nt, stream);
+}
+int mfgpu_vec_dot(const void *v, const void *w, size_t n, int nt, void *stream, double *result) {
+  return vec_reduce(0, const_cast<void *>(v), nullptr, w, 0.0, n, nt, stream, result);
+}
+int mfgpu_vec_l2_norm(const void *v, size_t n, int nt, void *stream, double *result) {
+  int rc = vec_reduce(0, const_cast<void *>(v), nullptr, v, 0.0, n, nt, stream, result);
+  if (!rc) *result = std::sqrt(*result);
+  return rc;
+}
+int mfgpu_vec_add_and_dot(void *v, double a, const void *x, const void *w, size_t n, int nt, void *stream,
+                          double *result) {
+  return vec_reduce(1, v, x, w, a, n, nt, stream, result);
+}
+int mfgpu_vec_all_zero(const void *v, size_t n, int nt, void *stream, int *result) {
+  if (!result) return MFGPU_EINVAL;
+  double cnt = 0.0;
+  int rc = vec_reduce(2, const_cast<void *>(v), nullptr, nullptr, 0.0, n, nt, stream, &cnt);
+  if (!rc) *result = cnt == 0.0;
+  return rc;
+}
 
 int mfgpu_vec_alloc(void **dev, size_t n, int nt) {
   if (!dev) return MFGPU_EINVAL;

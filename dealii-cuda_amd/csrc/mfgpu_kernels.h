@@ -74,5 +74,19 @@ hipError_t fold_launch(T *c, const T *coef, const T *jxw, const T *j0, const uin
 template <typename T>
 hipError_t fill_launch(T *v, size_t n, T a, hipStream_t st);
 
+// ---- SURVEY.md 8(f) N1 / N2 (mfgpu_aux.hip)
+template <typename T>
+hipError_t diag_launch(int dim, int n, T *diag, uint32_t n_batches, const uint32_t *batch_cell_off,
+                       const uint32_t *batch_dof_off, const uint32_t *bdofs, const uint16_t *lmap, const T *coef,
+                       const uint32_t *cmask, const T *hn_weights, const T *tab2, hipStream_t st);
+template <typename T>
+hipError_t set_values_launch(T *v, const uint32_t *idx, uint32_t n, T value, hipStream_t st);
+// op: 0 sadd (v = s v + a w), 1 equ (v = a w), 2 scale (v *= w), 3 divide (v /= w), 4 invert, 5 mul (v *= a)
+template <typename T>
+hipError_t vec_map_launch(int op, T *v, const T *w, T s, T a, size_t n, hipStream_t st);
+// op: 0 dot (v . w), 1 add_and_dot (v += a x; v . w), 2 count of non-zeros; blocking, result on the host
+template <typename T>
+hipError_t vec_reduce_launch(int op, T *v, const T *x, const T *w, T a, size_t n, hipStream_t st, double *out);
+
 }  // namespace mfgpu
 #endif

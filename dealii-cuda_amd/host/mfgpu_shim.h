@@ -146,9 +146,74 @@ public:
   }
   unsigned int memory_consumption() const { return _size * sizeof(Number); }
 
+  // ---- BLAS-1 and reductions (gpu_vec.h:105-157)
+  Number operator*(const GpuVector &v) const {  // scalar product
+    double r = 0;
+    check(mfgpu_vec_dot(vec_dev, v.vec_dev, _size, number_type<Number>(), nullptr, &r), "GpuVector::operator*");
+    return (Number)r;
+  }
+  void add(const GpuVector &V) { sadd(1, 1, V); }
+  void add(const Number a, const GpuVector &V) { sadd(1, a, V); }
+  void sadd(const Number s, const GpuVector &V) { sadd(s, 1, V); }
+  void sadd(const Number s, const Number a, const GpuVector &V) {  // this = s*this + a*V
+    check(mfgpu_vec_sadd(vec_dev, (double)s, (double)a, V.vec_dev, _size, number_type<Number>(), nullptr), "GpuVector::sadd");
+  }
+  GpuVector &operator+=(const GpuVector &x) { sadd(1, 1, x); return *this; }
+  GpuVector &operator-=(const GpuVector &x) { sadd(1, -1, x); return *this; }
+  Number add_and_dot(const Number a, const GpuVector &x, const GpuVector &v) {  // this += a*x; return this . v
+    double r = 0;
+    check(mfgpu_vec_add_and_dot(vec_dev, (double)a, x.vec_dev, v.vec_dev, _size, number_type<Number>(), nullptr, &r),
+          "GpuVector::add_and_dot");
+    return (Number)r;
+  }
+  void scale(const GpuVector &v) {  // element-wise multiplication
+    check(mfgpu_vec_scale(vec_dev, v.vec_dev, _size, number_type<Number>(), nullptr), "GpuVector::scale");
+  }
+  GpuVector &operator/=(const GpuVector &x) {  // element-wise division
+    check(mfgpu_vec_divide(vec_dev, x.vec_dev, _size, number_type<Number>(), nullptr), "GpuVector::operator/=");
+    return *this;
+  }
+  GpuVector &invert() {
+    check(mfgpu_vec_invert(vec_dev, _size, number_type<Number>(), nullptr), "GpuVector::invert");
+    return *this;
+  }
+  void equ(const Number a, const GpuVector &x) {  // this = a*x
+    if (x._size != _size) reinit(x._size);
+    check(mfgpu_vec_equ(vec_dev, (double)a, x.vec_dev, _size, number_type<Number>(), nullptr), "GpuVector::equ");
+  }
+  GpuVector &operator*=(const Number a) {
+    check(mfgpu_vec_mul(vec_dev, (double)a, _size, number_type<Number>(), nullptr), "GpuVector::operator*=");
+    return *this;
+  }
+  Number l2_norm() const {
+    double r = 0;
+    check(mfgpu_vec_l2_norm(vec_dev, _size, number_type<Number>(), nullptr, &r), "GpuVector::l2_norm");
+    return (Number)r;
+  }
+  bool all_zero() const {
+    int r = 0;
+    check(mfgpu_vec_all_zero(vec_dev, _size, number_type<Number>(), nullptr, &r), "GpuVector::all_zero");
+    return r != 0;
+  }
+
 private:
   void *vec_dev = nullptr;
   unsigned int _size = 0;
+};
+
+// DiagonalMatrix<GpuVector<Number>> as poisson.cu:242-250 uses it: vmult = element-wise scaling
+template <typename Number>
+class DiagonalMatrix {
+public:
+  GpuVector<Number> &get_vector() { return diagonal; }
+  const GpuVector<Number> &get_vector() const { return diagonal; }
+  void vmult(GpuVector<Number> &dst, const GpuVector<Number> &src) const {
+    dst.equ(1, src);
+    dst.scale(diagonal);
+  }
+
+private:
+  GpuVector<Number> diagonal;
 };
 
 // ---- ConstraintHandlerGpu ---------------------------------------------------------------------
@@ -240,8 +305,20 @@ public:
   }
   void Tvmult_add(VectorType &dst, const VectorType &src) const { vmult_add(dst, src); }
   Number el(unsigned int, unsigned int) const { throw std::runtime_error("matrix-free: no element access"); }
-  void compute_diagonal() {  // laplace_operator_gpu.h:405-421: next row N1
-    throw std::runtime_error("compute_diagonal is not implemented yet (SURVEY.md 8f, N1)");
+  // laplace_operator_gpu.h:401-418: inverse diagonal, constrained rows 1
+  void compute_diagonal() {
+    if (!inverse_diagonal_matrix) inverse_diagonal_matrix = std::make_shared<DiagonalMatrix<Number>>();
+    VectorType &inv_diag = inverse_diagonal_matrix->get_vector();
+    inv_diag.reinit(m());
+    check(mfgpu_compute_inverse_diagonal(data.handle, inv_diag.getData(), nullptr), "compute_diagonal");
+    diagonal_is_available = true;
+  }
+  const std::shared_ptr<DiagonalMatrix<Number>> get_diagonal_inverse() const {  // :420-429
+    if (!diagonal_is_available) throw std::runtime_error("get_diagonal_inverse: call compute_diagonal first");
+    return inverse_diagonal_matrix;
+  }
+  void set_constrained_values(VectorType &v, Number value) const {  // constraint_handler_gpu.cu:126-137
+    check(mfgpu_set_constrained_values(data.handle, v.getData(), (double)value, nullptr), "set_constrained_values");
   }
   std::size_t memory_consumption() const {  // :434-445
     return data.memory_consumption() + constraint_handler.memory_consumption();
@@ -250,6 +327,8 @@ public:
 private:
   MatrixFreeGpu<dim, Number> data;
   mutable ConstraintHandlerGpu<Number> constraint_handler;
+  std::shared_ptr<DiagonalMatrix<Number>> inverse_diagonal_matrix;
+  bool diagonal_is_available = false;
 };
 
 }  // namespace mfgpu_shim

@@ -39,7 +39,9 @@ class Desc(C.Structure):
 # every symbol include/mfgpu.h declares (tests check that the library exports all of them)
 SYMBOLS = [
     "mfgpu_create", "mfgpu_vmult", "mfgpu_vmult_add", "mfgpu_n_dofs", "mfgpu_memory_consumption",
-    "mfgpu_destroy", "mfgpu_last_error", "mfgpu_plan_stats", "mfgpu_kernel_name", "mfgpu_profile_enable", "mfgpu_profile_read",
+    "mfgpu_destroy", "mfgpu_last_error", "mfgpu_plan_stats", "mfgpu_kernel_name", "mfgpu_compute_inverse_diagonal", "mfgpu_set_constrained_values",
+    "mfgpu_vec_sadd", "mfgpu_vec_equ", "mfgpu_vec_scale", "mfgpu_vec_divide", "mfgpu_vec_invert", "mfgpu_vec_mul",
+    "mfgpu_vec_dot", "mfgpu_vec_l2_norm", "mfgpu_vec_add_and_dot", "mfgpu_vec_all_zero", "mfgpu_profile_enable", "mfgpu_profile_read",
     "mfgpu_plan_create", "mfgpu_plan_destroy", "mfgpu_plan_array_u32", "mfgpu_plan_lmap", "mfgpu_plan_bflags",
     "mfgpu_vec_alloc", "mfgpu_vec_free", "mfgpu_vec_fill", "mfgpu_vec_from_host", "mfgpu_vec_to_host",
     "mfgpu_device_synchronize", "mfgpu_mesh_create_uniform", "mfgpu_mesh_create_adaptive", "mfgpu_mesh_create_from_leaves",
@@ -70,6 +72,19 @@ def lib():
         L.mfgpu_plan_stats.argtypes = [C.c_void_p, C.POINTER(C.c_uint64)]
         L.mfgpu_kernel_name.argtypes = [C.c_void_p]
         L.mfgpu_kernel_name.restype = C.c_char_p
+        L.mfgpu_compute_inverse_diagonal.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p]
+        L.mfgpu_set_constrained_values.argtypes = [C.c_void_p, C.c_void_p, C.c_double, C.c_void_p]
+        vp, d, z, i = C.c_void_p, C.c_double, C.c_size_t, C.c_int
+        L.mfgpu_vec_sadd.argtypes = [vp, d, d, vp, z, i, vp]
+        L.mfgpu_vec_equ.argtypes = [vp, d, vp, z, i, vp]
+        L.mfgpu_vec_scale.argtypes = [vp, vp, z, i, vp]
+        L.mfgpu_vec_divide.argtypes = [vp, vp, z, i, vp]
+        L.mfgpu_vec_invert.argtypes = [vp, z, i, vp]
+        L.mfgpu_vec_mul.argtypes = [vp, d, z, i, vp]
+        L.mfgpu_vec_dot.argtypes = [vp, vp, z, i, vp, C.POINTER(d)]
+        L.mfgpu_vec_l2_norm.argtypes = [vp, z, i, vp, C.POINTER(d)]
+        L.mfgpu_vec_add_and_dot.argtypes = [vp, d, vp, vp, z, i, vp, C.POINTER(d)]
+        L.mfgpu_vec_all_zero.argtypes = [vp, z, i, vp, C.POINTER(i)]
         L.mfgpu_profile_enable.argtypes = [C.c_void_p, C.c_int]
         L.mfgpu_profile_read.argtypes = [C.c_void_p, C.POINTER(C.c_double), C.POINTER(C.c_uint64)]
         L.mfgpu_plan_create.argtypes = [C.POINTER(Desc), C.POINTER(C.c_void_p)]
@@ -318,6 +333,54 @@ class DeviceVector:
         self.ptr, other.ptr = other.ptr, self.ptr
         self.n, other.n = other.n, self.n
 
+    # ---- GpuVector BLAS-1 and reductions (gpu_vec.h:105-157), SURVEY.md 8(f) N2
+    def _a(self, other=None):
+        if other is not None:
+            assert other.n == self.n and other.number_type == self.number_type
+        return self.n, self.number_type
+
+    def sadd(self, s, a, w, stream=None):      # this = s*this + a*w
+        _check(lib().mfgpu_vec_sadd(self.ptr, float(s), float(a), w.ptr, *self._a(w), stream))
+
+    def add(self, a, w, stream=None):          # this += a*w
+        self.sadd(1.0, a, w, stream)
+
+    def equ(self, a, w, stream=None):          # this = a*w
+        _check(lib().mfgpu_vec_equ(self.ptr, float(a), w.ptr, *self._a(w), stream))
+
+    def scale(self, w, stream=None):           # this[i] *= w[i]
+        _check(lib().mfgpu_vec_scale(self.ptr, w.ptr, *self._a(w), stream))
+
+    def divide(self, w, stream=None):          # operator/=
+        _check(lib().mfgpu_vec_divide(self.ptr, w.ptr, *self._a(w), stream))
+
+    def invert(self, stream=None):
+        _check(lib().mfgpu_vec_invert(self.ptr, *self._a(), stream))
+
+    def mul(self, a, stream=None):             # operator*=
+        _check(lib().mfgpu_vec_mul(self.ptr, float(a), *self._a(), stream))
+
+    def dot(self, w, stream=None):             # operator*
+        r = C.c_double()
+        _check(lib().mfgpu_vec_dot(self.ptr, w.ptr, *self._a(w), stream, C.byref(r)))
+        return r.value
+
+    def l2_norm(self, stream=None):
+        r = C.c_double()
+        _check(lib().mfgpu_vec_l2_norm(self.ptr, *self._a(), stream, C.byref(r)))
+        return r.value
+
+    def add_and_dot(self, a, x, w, stream=None):  # this += a*x; return this . w
+        r = C.c_double()
+        self._a(x)
+        _check(lib().mfgpu_vec_add_and_dot(self.ptr, float(a), x.ptr, w.ptr, *self._a(w), stream, C.byref(r)))
+        return r.value
+
+    def all_zero(self, stream=None):
+        r = C.c_int()
+        _check(lib().mfgpu_vec_all_zero(self.ptr, *self._a(), stream, C.byref(r)))
+        return bool(r.value)
+
 
 class Operator:
     """LaplaceOperatorGpu surface over the C-ABI handle."""
@@ -360,6 +423,14 @@ class Operator:
 
     def kernel_name(self):
         return lib().mfgpu_kernel_name(self._h).decode()
+
+    def compute_inverse_diagonal(self, inv_diag, stream=None):
+        """LaplaceOperatorGpu::compute_diagonal + get_diagonal_inverse (laplace_operator_gpu.h:401-429)"""
+        _check(lib().mfgpu_compute_inverse_diagonal(self._h, _ptr(inv_diag), stream))
+
+    def set_constrained_values(self, vec, value, stream=None):
+        """ConstraintHandlerGpu::set_constrained_values (constraint_handler_gpu.cu:126-137)"""
+        _check(lib().mfgpu_set_constrained_values(self._h, _ptr(vec), float(value), stream))
 
     def profile_enable(self, on=True):
         _check(lib().mfgpu_profile_enable(self._h, int(on)))

@@ -140,6 +140,32 @@ int64_t mfgpu_plan_array_u32(const mfgpu_plan *p, int what, const uint32_t **ptr
 int64_t mfgpu_plan_lmap(const mfgpu_plan *p, const uint16_t **ptr);   /* [n_cells*n^dim], plan order */
 int64_t mfgpu_plan_bflags(const mfgpu_plan *p, const uint8_t **ptr);  /* bit0 constrained, bit1 add */
 
+/* ---- what a CG / Chebyshev caller needs from the operator besides vmult -------------
+ * LaplaceOperatorGpu::compute_diagonal + get_diagonal_inverse (laplace_operator_gpu.h:401-429): writes
+ * 1 / diag(A) into inv_diag[n_dofs] (device, operator's number type); the local diagonal of every cell
+ * (DiagonalLocalOperator, :355-399) is distributed like a cell result, including the transposed hanging-node
+ * resolution, constrained rows are set to 1 before the inversion (:412-414).                              */
+int mfgpu_compute_inverse_diagonal(mfgpu_handle *h, void *inv_diag, void *stream);
+/* ConstraintHandlerGpu::set_constrained_values (constraint_handler_gpu.cu:126-137): vec[c] = value for every
+ * constrained dof c of the description.                                                                   */
+int mfgpu_set_constrained_values(mfgpu_handle *h, void *vec, double value, void *stream);
+
+/* ---- GpuVector BLAS-1 and reductions (gpu_vec.h:105-157, gpu_vec.cu:222-617) -------
+ * v, w, x: device vectors of n elements of number_type.  The element-wise operations are asynchronous on
+ * `stream`; the reductions block until the result is on the host (as the reference's do, gpu_vec.cu:556-560)
+ * and accumulate in double in a fixed order (deterministic).                                               */
+int mfgpu_vec_sadd(void *v, double s, double a, const void *w, size_t n, int number_type, void *stream);  /* v = s v + a w   gpu_vec.cu:308-314 */
+int mfgpu_vec_equ(void *v, double a, const void *w, size_t n, int number_type, void *stream);             /* v = a w         :346-352 */
+int mfgpu_vec_scale(void *v, const void *w, size_t n, int number_type, void *stream);                     /* v[i] *= w[i]    :320-325 */
+int mfgpu_vec_divide(void *v, const void *w, size_t n, int number_type, void *stream);                    /* v[i] /= w[i]    :328-333 */
+int mfgpu_vec_invert(void *v, size_t n, int number_type, void *stream);                                   /* v[i] = 1/v[i]   :336-342 */
+int mfgpu_vec_mul(void *v, double a, size_t n, int number_type, void *stream);                            /* v *= a          :357-362 */
+int mfgpu_vec_dot(const void *v, const void *w, size_t n, int number_type, void *stream, double *result); /* v . w           :542-563 */
+int mfgpu_vec_l2_norm(const void *v, size_t n, int number_type, void *stream, double *result);            /* sqrt(v . v)     :367-369 */
+int mfgpu_vec_add_and_dot(void *v, double a, const void *x, const void *w, size_t n, int number_type,
+                          void *stream, double *result);                              /* v += a x; return v . w   :597-617 */
+int mfgpu_vec_all_zero(const void *v, size_t n, int number_type, void *stream, int *result);              /* :512-540 */
+
 /* ---- GpuVector pieces that are on the path (gpu_vec.h:44,69,84-88,164-172) -------------- */
 int mfgpu_vec_alloc(void **dev, size_t n, int number_type);               /* gpu_vec.cu:166-182, zero-filled */
 int mfgpu_vec_free(void *dev);
