@@ -40,9 +40,11 @@ struct Plan {
   // to a halo buffer slot and are summed per dof by a second kernel in fixed batch order
   std::vector<uint32_t> batch_nint;       // [n_batches] number of interior dofs of the batch
   std::vector<uint32_t> halo_off;         // [n_batches+1] first halo slot of the batch's shared dofs
-  std::vector<uint32_t> sdofs;            // [n_shared] ascending global ids; bit 31 = constrained
+  std::vector<uint32_t> sdofs;            // [n_shared] global ids grouped by toucher set; bit 31 = constrained
   std::vector<uint32_t> s_off;            // [n_shared+1] CSR into s_idx
   std::vector<uint32_t> s_idx;            // halo slots of the partial sums, ascending batch order
+  std::vector<uint32_t> chunks;           // [4 * n_chunks] {sdofs position, count | k << 16, gstarts offset, offset in group}
+  std::vector<uint32_t> gstarts;          // per group: halo slot of its first dof in each of its k touchers
   uint32_t max_batch_dofs = 0, max_batch_cells = 0;
   uint64_t n_first = 0, n_add = 0;
 };

@@ -52,6 +52,9 @@ hipError_t apply_occupancy(int dim, int n, bool hn, bool twopass, bool wave, siz
 template <typename T>
 hipError_t reduce_launch(T *dst, const T *src, const T *halo, const uint32_t *sdofs, const uint32_t *s_off,
                          const uint32_t *s_idx, uint32_t ns, int add, hipStream_t st);
+template <typename T>
+hipError_t reduce_groups_launch(T *dst, const T *src, const T *halo, const uint32_t *sdofs, const uint32_t *chunks,
+                                const uint32_t *gstarts, uint32_t nchunks, int add, hipStream_t st);
 // experimental plane-per-thread kernel (3D, n <= 5, two-pass mode, no hanging nodes)
 template <typename T>
 hipError_t plane_launch(int n, const ApplyArgs<T> &a, const double *S, const double *Dt, uint32_t grid,

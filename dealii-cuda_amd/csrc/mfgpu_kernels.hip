@@ -337,6 +337,34 @@ reduce_shared(T *__restrict__ dst, const T *__restrict__ src, const T *__restric
   dst[g] = add ? dst[g] + val : val;
 }
 
+// Second pass, grouped form (mfgpu_plan.cpp): one wave per chunk of up to 64 consecutive dofs of one
+// toucher group.  The k partial sums of lane l are halo[gstarts[tstart + t] + offset + l]: k coalesced runs,
+// no per-partial index (the CSR form above reads one 32-bit slot index per partial and gathers).  Same
+// summation order (ascending batch), so both forms give bit-identical results.
+template <typename T>
+__global__ void __launch_bounds__(256)
+reduce_groups(T *__restrict__ dst, const T *__restrict__ src, const T *__restrict__ halo,
+              const uint32_t *__restrict__ sdofs, const uint4 *__restrict__ chunks,
+              const uint32_t *__restrict__ gstarts, uint32_t nchunks, int add) {
+  const uint32_t c = blockIdx.x * 4u + (threadIdx.x >> 6);
+  if (c >= nchunks) return;
+  const uint4 d = chunks[c];
+  const uint32_t lane = threadIdx.x & 63u, cnt = d.y & 0xffffu, k = d.y >> 16;
+  if (lane >= cnt) return;
+  const uint32_t o = sdofs[d.x + lane];
+  const uint32_t g = o & 0x7fffffffu;
+  T val;
+  if (o >> 31) {
+    val = src[g];
+  } else {
+    const uint32_t *gs = gstarts + d.z;
+    const uint32_t off = d.w + lane;
+    val = halo[gs[0] + off];
+    for (uint32_t t = 1; t < k; ++t) val += halo[gs[t] + off];
+  }
+  dst[g] = add ? dst[g] + val : val;
+}
+
 // =============================================================================================
 // Plane kernel (3D, n <= 5, no hanging nodes): a thread owns a 2D PLANE of the cell (n*n values in
 // registers), so two of the three contraction directions are register mat-vecs and a cell needs 3
@@ -825,6 +853,15 @@ hipError_t reduce_launch(T *dst, const T *src, const T *halo, const uint32_t *sd
 }
 
 template <typename T>
+hipError_t reduce_groups_launch(T *dst, const T *src, const T *halo, const uint32_t *sdofs, const uint32_t *chunks,
+                                const uint32_t *gstarts, uint32_t nchunks, int add, hipStream_t st) {
+  if (nchunks == 0) return hipSuccess;
+  hipLaunchKernelGGL(reduce_groups<T>, dim3((nchunks + 3) / 4), dim3(256), 0, st, dst, src, halo, sdofs,
+                     reinterpret_cast<const uint4 *>(chunks), gstarts, nchunks, add);
+  return hipGetLastError();
+}
+
+template <typename T>
 hipError_t orphan_launch(T *dst, const T *src, const uint32_t *orph, uint32_t n, int add,
                          hipStream_t st) {
   if (n == 0) return hipSuccess;
@@ -870,6 +907,8 @@ hipError_t fill_launch(T *v, size_t n, T a, hipStream_t st) {
                                       bool, bool, bool, uint32_t, hipStream_t);                         \
   template hipError_t reduce_launch<T>(T *, const T *, const T *, const uint32_t *, const uint32_t *,   \
                                        const uint32_t *, uint32_t, int, hipStream_t);                   \
+  template hipError_t reduce_groups_launch<T>(T *, const T *, const T *, const uint32_t *, const uint32_t *, \
+                                              const uint32_t *, uint32_t, int, hipStream_t);            \
   template hipError_t orphan_launch<T>(T *, const T *, const uint32_t *, uint32_t, int, hipStream_t);   \
   template hipError_t coefficient_launch<T>(T *, const T *, size_t, int, hipStream_t);                  \
   template hipError_t fold_launch<T>(T *, const T *, const T *, const T *, const uint32_t *, uint32_t,  \

@@ -205,8 +205,8 @@ int build_plan(const mfgpu_desc &d, Plan &P) {
     for (auto &cells : batches)
       std::stable_partition(cells.begin(), cells.end(), [&](uint32_t c) { return d.constraint_mask[c] != 0; });
 
-  // ---- per batch: unique dofs, ordered [interior ascending | shared ascending] where interior =
-  // touched by this batch only
+  // ---- per batch: unique dofs, ordered [interior ascending | shared] where interior = touched by this
+  // batch only (the shared part is re-ordered by toucher group below)
   std::vector<std::vector<uint32_t>> bd(nb);
   std::vector<uint32_t> ntouch(N, 0);
   for (uint32_t b = 0; b < nb; ++b) {
@@ -266,6 +266,49 @@ int build_plan(const mfgpu_desc &d, Plan &P) {
     P.color_batch_off.assign({0u, nb});
   }
 
+  // ---- shared dofs, grouped by toucher set.  All dofs that are shared by the same set of batches (the
+  // interior of a face between two batches, of an edge between four, a vertex between eight) form a
+  // GROUP.  The global shared list (pass 2 walks it) is sorted by (toucher sequence in execution order,
+  // global id) and every batch lists its shared dofs in that same order, so a group occupies ONE
+  // contiguous run of halo slots in each of its touchers, with identical dof order: pass 2 reads the
+  // partial sums of a group as k coalesced runs and needs no per-partial index.
+  std::vector<uint32_t> rank_of(nb);
+  for (uint32_t k = 0; k < nb; ++k) rank_of[order[k]] = k;
+  std::vector<uint32_t> shared_ids;
+  for (uint32_t g = 0; g < N; ++g)
+    if (ntouch[g] >= 2) shared_ids.push_back(g);
+  const size_t ns = shared_ids.size();
+  std::vector<uint32_t> sid(N, NONE), t_off(ns + 1, 0);
+  for (size_t i = 0; i < ns; ++i) {
+    sid[shared_ids[i]] = (uint32_t)i;
+    t_off[i + 1] = t_off[i] + ntouch[shared_ids[i]];
+  }
+  std::vector<uint32_t> touchers(t_off[ns]);
+  {
+    std::vector<uint32_t> fill(t_off.begin(), t_off.end() - 1);
+    for (uint32_t k = 0; k < nb; ++k)  // ascending execution position
+      for (size_t t = nint[order[k]]; t < bd[order[k]].size(); ++t) touchers[fill[sid[bd[order[k]][t]]]++] = k;
+  }
+  auto seq_less = [&](uint32_t a, uint32_t b2) {  // a, b2: indices into shared_ids
+    const uint32_t la = t_off[a + 1] - t_off[a], lb = t_off[b2 + 1] - t_off[b2];
+    const uint32_t *pa = &touchers[t_off[a]], *pb = &touchers[t_off[b2]];
+    for (uint32_t i = 0; i < la && i < lb; ++i)
+      if (pa[i] != pb[i]) return pa[i] < pb[i];
+    if (la != lb) return la < lb;
+    return a < b2;  // same group: ascending global id
+  };
+  auto same_group = [&](uint32_t a, uint32_t b2) {
+    const uint32_t la = t_off[a + 1] - t_off[a], lb = t_off[b2 + 1] - t_off[b2];
+    return la == lb && std::equal(&touchers[t_off[a]], &touchers[t_off[a]] + la, &touchers[t_off[b2]]);
+  };
+  std::vector<uint32_t> sorder(ns);
+  std::iota(sorder.begin(), sorder.end(), 0u);
+  std::sort(sorder.begin(), sorder.end(), seq_less);
+  std::vector<uint32_t> spos(N, NONE);  // global id -> position in the grouped shared list
+  for (size_t i = 0; i < ns; ++i) spos[shared_ids[sorder[i]]] = (uint32_t)i;
+  for (uint32_t b = 0; b < nb; ++b)
+    std::sort(bd[b].begin() + nint[b], bd[b].end(), [&](uint32_t x, uint32_t y) { return spos[x] < spos[y]; });
+
   // ---- emit arrays in execution order
   P.cell_order.clear();
   P.cell_order.reserve(nc);
@@ -275,6 +318,7 @@ int build_plan(const mfgpu_desc &d, Plan &P) {
   P.bflags.clear();
   P.lmap.assign((size_t)nc * nd, 0);
   std::vector<uint8_t> touched(N, 0);
+  std::vector<uint16_t> pos_in_batch(N, 0);
   P.max_batch_dofs = P.max_batch_cells = 0;
   P.n_first = P.n_add = 0;
   P.batch_nint.clear();
@@ -297,15 +341,11 @@ int build_plan(const mfgpu_desc &d, Plan &P) {
       P.bdofs.push_back(g | (constrained[g] ? 0x80000000u : 0u));  // bit 31: constrained row
       P.bflags.push_back(f);
     }
+    for (size_t t = 0; t < v.size(); ++t) pos_in_batch[v[t]] = (uint16_t)t;  // valid for this batch's dofs only
     for (uint32_t c : batches[b]) {
       const size_t pos = P.cell_order.size();
       P.cell_order.push_back(c);
-      for (uint32_t i = 0; i < nd; ++i) {
-        const uint32_t g = l2g[(uint64_t)c * nd + i];
-        const auto first = ntouch[g] == 1 ? v.begin() : v.begin() + nint[b];
-        const auto last = ntouch[g] == 1 ? v.begin() + nint[b] : v.end();
-        P.lmap[pos * nd + i] = (uint16_t)(std::lower_bound(first, last, g) - v.begin());
-      }
+      for (uint32_t i = 0; i < nd; ++i) P.lmap[pos * nd + i] = pos_in_batch[l2g[(uint64_t)c * nd + i]];
     }
     P.batch_cell_off.push_back((uint32_t)P.cell_order.size());
     P.batch_dof_off.push_back((uint32_t)P.bdofs.size());
@@ -315,16 +355,17 @@ int build_plan(const mfgpu_desc &d, Plan &P) {
   P.orphans.clear();
   for (uint32_t g = 0; g < N; ++g)
     if (!touched[g]) P.orphans.push_back(g | (constrained[g] ? 0x80000000u : 0u));
-  // shared-dof CSR for the second pass: halo slots in ascending execution order of the batches
+  // ---- second pass.  sdofs: the grouped shared list.  (s_off, s_idx): CSR of the halo slots of every
+  // shared dof in ascending execution order of the batches -- the generic form, used by the host-side
+  // checks and by reduce_shared when the groups are too small to pay (irregular meshes).  (chunks,
+  // gstarts): the grouped form -- a chunk is up to 64 consecutive dofs of one group; its k partial sums
+  // per dof sit at gstarts[tstart + t] + offset + lane, t = 0..k-1.
   {
-    std::vector<uint32_t> sid(N, NONE);
-    P.sdofs.clear();
-    for (uint32_t g = 0; g < N; ++g)
-      if (ntouch[g] >= 2) {
-        sid[g] = (uint32_t)P.sdofs.size();
-        P.sdofs.push_back(g | (constrained[g] ? 0x80000000u : 0u));
-      }
-    const size_t ns = P.sdofs.size();
+    P.sdofs.resize(ns);
+    for (size_t i = 0; i < ns; ++i) {
+      const uint32_t g = shared_ids[sorder[i]];
+      P.sdofs[i] = g | (constrained[g] ? 0x80000000u : 0u);
+    }
     P.s_off.assign(ns + 1, 0);
     for (size_t i = 0; i < ns; ++i) P.s_off[i + 1] = P.s_off[i] + ntouch[P.sdofs[i] & 0x7fffffffu];
     P.s_idx.assign(P.s_off[ns], 0);
@@ -334,8 +375,24 @@ int build_plan(const mfgpu_desc &d, Plan &P) {
       const uint32_t d0 = P.batch_dof_off[k], d1 = P.batch_dof_off[k + 1];
       for (uint32_t t = d0 + ni; t < d1; ++t) {
         const uint32_t g = P.bdofs[t] & 0x7fffffffu;
-        P.s_idx[fill[sid[g]]++] = P.halo_off[k] + (t - d0 - ni);
+        P.s_idx[fill[spos[g]]++] = P.halo_off[k] + (t - d0 - ni);
       }
+    }
+    P.chunks.clear();
+    P.gstarts.clear();
+    for (size_t i = 0; i < ns;) {
+      size_t j = i + 1;
+      while (j < ns && same_group(sorder[i], sorder[j])) ++j;
+      const uint32_t k = P.s_off[i + 1] - P.s_off[i], tstart = (uint32_t)P.gstarts.size();
+      for (uint32_t t = 0; t < k; ++t) P.gstarts.push_back(P.s_idx[P.s_off[i] + t]);  // first dof's slots
+      for (size_t o = i; o < j; o += 64) {
+        const uint32_t cnt = (uint32_t)std::min<size_t>(64, j - o);
+        P.chunks.push_back((uint32_t)o);
+        P.chunks.push_back(cnt | (k << 16));
+        P.chunks.push_back(tstart);
+        P.chunks.push_back((uint32_t)(o - i));
+      }
+      i = j;
     }
   }
   return 0;
@@ -379,6 +436,8 @@ int64_t mfgpu_plan_array_u32(const mfgpu_plan *p, int what, const uint32_t **ptr
     case 8: v = &p->plan.sdofs; break;
     case 9: v = &p->plan.s_off; break;
     case 10: v = &p->plan.s_idx; break;
+    case 11: v = &p->plan.chunks; break;
+    case 12: v = &p->plan.gstarts; break;
     default: mfgpu::set_error("bad array id"); return MFGPU_EINVAL;
   }
   *ptr = v->data();

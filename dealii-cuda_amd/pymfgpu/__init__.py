@@ -288,6 +288,8 @@ class Plan:
     sdofs = property(lambda s: s._u32(8))
     s_off = property(lambda s: s._u32(9))
     s_idx = property(lambda s: s._u32(10))
+    chunks = property(lambda s: s._u32(11).reshape(-1, 4))   # {sdofs position, count | k << 16, gstarts offset, offset in group}
+    gstarts = property(lambda s: s._u32(12))
 
     @property
     def lmap(self):

@@ -56,7 +56,7 @@ def test_vmult_matches_oracle(dim, p, n, nt, colored):
     assert rel(y, o.vmult(od, x.astype(mf.np_dtype(nt)).astype(np.float64))) <= TOL[nt]
 
 
-KNOBS = [("MFGPU_X", "0", "apply_batches"), ("MFGPU_LS", "1", "apply_batches_ls"),
+KNOBS = [("MFGPU_X", "0", "apply_batches"), ("MFGPU_GROUPS", "0", "apply_batches_x"), ("MFGPU_LS", "1", "apply_batches_ls"),
          ("MFGPU_WAVE", "1", "apply_batches"), ("MFGPU_PLANE", "1", "apply_planes")]
 
 
@@ -70,7 +70,7 @@ def test_kernel_variants_match_oracle(knob, value, kernel, dim, p, n, monkeypatc
     od = oracle_desc_from_mesh(mesh, dtype=np.float64)
     op = mf.Operator(mesh.desc, mesh)
     if dim == 3 and knob != "MFGPU_LS":
-        assert op.kernel_name() == kernel
+        assert op.kernel_name() == kernel  # (MFGPU_GROUPS=0: per-dof CSR form of pass 2 instead of the grouped one)
     rng = np.random.default_rng(17)
     x, y0 = rng.standard_normal(mesh.n_dofs), rng.standard_normal(mesh.n_dofs)
     assert rel(gpu_vmult(op, x), o.vmult(od, x)) <= 1e-12

@@ -85,17 +85,29 @@ def _plan_invariants(od, plan, colored=False):
         ntouch[bdofs[bdo[b]:bdo[b + 1]]] += 1
     # shared-dof CSR of the two-pass mode
     sd, so, si = plan.sdofs, plan.s_off, plan.s_idx
-    np.testing.assert_array_equal(sd & 0x7fffffff, np.nonzero(ntouch >= 2)[0])
+    np.testing.assert_array_equal(np.sort(sd & 0x7fffffff), np.nonzero(ntouch >= 2)[0])
     np.testing.assert_array_equal(np.diff(so), ntouch[sd & 0x7fffffff])
     assert sorted(si.tolist()) == list(range(int(plan.halo_off[-1])))   # every halo slot read exactly once
+    # grouped form of the same pass: chunks of <= 64 consecutive shared dofs with one toucher set; partial t
+    # of the chunk's lane l sits at gstarts[tstart + t] + offset + l -- must reproduce the CSR exactly
+    ch, gs = plan.chunks, plan.gstarts
+    covered = np.zeros(len(sd), int)
+    for pos, ck, ts, off in ch.tolist():
+        cnt, k = ck & 0xffff, ck >> 16
+        assert 1 <= cnt <= 64 and k >= 2
+        covered[pos:pos + cnt] += 1
+        for lane in range(cnt):
+            i = pos + lane
+            assert so[i + 1] - so[i] == k
+            np.testing.assert_array_equal(si[so[i]:so[i + 1]], gs[ts:ts + k] + off + lane)
+    assert (covered == 1).all()
     for c in range(len(cbo) - 1):
         seen = np.zeros(od.n_dofs, bool)
         for b in range(cbo[c], cbo[c + 1]):
             g = bdofs[bdo[b]:bdo[b + 1]]
             f = bflags[bdo[b]:bdo[b + 1]]
             ni = int(plan.batch_nint[b])
-            assert (np.diff(g[:ni].astype(np.int64)) > 0).all()     # [interior asc | shared asc], unique
-            assert (np.diff(g[ni:].astype(np.int64)) > 0).all()
+            assert (np.diff(g[:ni].astype(np.int64)) > 0).all()     # [interior asc | shared, grouped], unique
             assert len(np.unique(g)) == len(g)
             assert (ntouch[g[:ni]] == 1).all() and (ntouch[g[ni:]] >= 2).all()
             assert plan.halo_off[b + 1] - plan.halo_off[b] == len(g) - ni
