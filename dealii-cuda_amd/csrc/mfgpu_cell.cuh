@@ -194,15 +194,16 @@ __device__ __forceinline__ void cell_pipeline(const bool act, const int pa, cons
         lds_store<n>(Wc + bx, 1, u);
       }
       Sync::sync();
-      if (act) {
+      // only the pencils on a constrained face or edge change: everybody else skips the round trip
+      if (act && mask && hn_flag3<n, 1>(mask, pb, pa, type)) {
         lds_load<n>(Wc + by, n, u);
-        if (mask && hn_flag3<n, 1>(mask, pb, pa, type)) hn_pencil<n, T, false>(Wl, type, u);
+        hn_pencil<n, T, false>(Wl, type, u);
         lds_store<n>(Wc + by, n, u);
       }
       Sync::sync();
-      if (act) {
+      if (act && mask && hn_flag3<n, 2>(mask, pa, pb, type)) {
         lds_load<n>(Wc + bz, n2, u);
-        if (mask && hn_flag3<n, 2>(mask, pa, pb, type)) hn_pencil<n, T, false>(Wl, type, u);
+        hn_pencil<n, T, false>(Wl, type, u);
         lds_store<n>(Wc + bz, n2, u);
       }
       Sync::sync();
@@ -292,9 +293,9 @@ __device__ __forceinline__ void cell_pipeline(const bool act, const int pa, cons
         lds_store<n>(Rc + bz, n2, v);
       }
       Sync::sync();
-      if (act) {
+      if (act && mask && hn_flag3<n, 1>(mask, pb, pa, type)) {
         lds_load<n>(Rc + by, n, v);
-        if (mask && hn_flag3<n, 1>(mask, pb, pa, type)) hn_pencil<n, T, true>(Wl, type, v);
+        hn_pencil<n, T, true>(Wl, type, v);
         lds_store<n>(Rc + by, n, v);
       }
       Sync::sync();
@@ -317,9 +318,9 @@ __device__ __forceinline__ void cell_pipeline(const bool act, const int pa, cons
         lds_store<n>(Wc + bx, 1, u);
       }
       Sync::sync();
-      if (act) {
+      if (act && mask && hn_flag2<n, 1>(mask, pa, type)) {
         lds_load<n>(Wc + by, n, u);
-        if (mask && hn_flag2<n, 1>(mask, pa, type)) hn_pencil<n, T, false>(Wl, type, u);
+        hn_pencil<n, T, false>(Wl, type, u);
         lds_store<n>(Wc + by, n, u);
       }
       Sync::sync();

@@ -57,15 +57,16 @@ __device__ __forceinline__ void cell_pipeline_x(const bool act, const int pa, co
       lds_store<n>(Wc + bx, 1, u);
     }
     __syncthreads();
-    if (act) {
+    // only the pencils on a constrained face or edge change: everybody else skips the round trip
+    if (act && mask && hn_flag3<n, 1>(mask, pb, pa, type)) {
       lds_load<n>(Wc + by, n, u);
-      if (mask && hn_flag3<n, 1>(mask, pb, pa, type)) hn_pencil<n, T, false>(Wl, type, u);
+      hn_pencil<n, T, false>(Wl, type, u);
       lds_store<n>(Wc + by, n, u);
     }
     __syncthreads();
-    if (act) {
+    if (act && mask && hn_flag3<n, 2>(mask, pa, pb, type)) {
       lds_load<n>(Wc + bz, n2, u);
-      if (mask && hn_flag3<n, 2>(mask, pa, pb, type)) hn_pencil<n, T, false>(Wl, type, u);
+      hn_pencil<n, T, false>(Wl, type, u);
       lds_store<n>(Wc + bz, n2, u);
     }
     __syncthreads();
@@ -145,15 +146,15 @@ __device__ __forceinline__ void cell_pipeline_x(const bool act, const int pa, co
     bool type;
     if (act) lds_store<n>(Rc + bx, 1, v);
     __syncthreads();
-    if (act) {
+    if (act && mask && hn_flag3<n, 1>(mask, pb, pa, type)) {
       lds_load<n>(Rc + by, n, v);
-      if (mask && hn_flag3<n, 1>(mask, pb, pa, type)) hn_pencil<n, T, true>(Wl, type, v);
+      hn_pencil<n, T, true>(Wl, type, v);
       lds_store<n>(Rc + by, n, v);
     }
     __syncthreads();
-    if (act) {
+    if (act && mask && hn_flag3<n, 2>(mask, pa, pb, type)) {
       lds_load<n>(Rc + bz, n2, v);
-      if (mask && hn_flag3<n, 2>(mask, pa, pb, type)) hn_pencil<n, T, true>(Wl, type, v);
+      hn_pencil<n, T, true>(Wl, type, v);
       lds_store<n>(Rc + bz, n2, v);
     }
     __syncthreads();
