@@ -214,11 +214,16 @@ apply_batches_x(const ApplyArgs<T> A, const Tables<T, n> tab) {
   uint32_t b, bstride, bend;
   {
     const uint32_t nbt = A.batch_end - A.batch0, G = gridDim.x;
-    if ((G & 7u) == 0 && nbt >= G) {
+    if (G >= 8 && nbt >= G) {
+      // XCD x runs the blocks i = x, x + 8, ...: w(x) = (G - x + 7) / 8 of them; its batch range is
+      // proportional to that count (any grid size, e.g. one that divides the batch count evenly)
       const uint32_t xcd = blockIdx.x & 7u, slot = blockIdx.x >> 3;
-      b = A.batch0 + (uint32_t)((uint64_t)nbt * xcd / 8) + slot;
-      bend = A.batch0 + (uint32_t)((uint64_t)nbt * (xcd + 1) / 8);
-      bstride = G >> 3;
+      const uint32_t q = G >> 3, rem = G & 7u;
+      const uint32_t wlo = xcd * q + (xcd < rem ? xcd : rem);  // blocks of the XCDs before this one
+      const uint32_t w = q + (xcd < rem ? 1u : 0u);
+      b = A.batch0 + (uint32_t)((uint64_t)nbt * wlo / G) + slot;
+      bend = A.batch0 + (uint32_t)((uint64_t)nbt * (wlo + w) / G);
+      bstride = w;
     } else {
       b = A.batch0 + blockIdx.x;
       bend = A.batch_end;

@@ -56,7 +56,9 @@ def test_vmult_matches_oracle(dim, p, n, nt, colored):
     assert rel(y, o.vmult(od, x.astype(mf.np_dtype(nt)).astype(np.float64))) <= TOL[nt]
 
 
-KNOBS = [("MFGPU_X", "0", "apply_batches"), ("MFGPU_GROUPS", "0", "apply_batches_x"), ("MFGPU_LS", "1", "apply_batches_ls"),
+KNOBS = [("MFGPU_X", "0", "apply_batches"), ("MFGPU_GROUPS", "0", "apply_batches_x"),
+         ("MFGPU_GRID", "13", "apply_batches_x"),  # persistent grid that is no multiple of the 8 XCDs
+         ("MFGPU_LS", "1", "apply_batches_ls"),
          ("MFGPU_WAVE", "1", "apply_batches"), ("MFGPU_PLANE", "1", "apply_planes")]
 
 
