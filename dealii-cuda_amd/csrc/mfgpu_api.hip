@@ -439,14 +439,9 @@ int mfgpu_create(const mfgpu_desc *desc, mfgpu_handle **out) {
   // experimental loader / compute wave split (slower than apply_batches: profiles/r01_notes.md)
   if (const char *e = getenv("MFGPU_LS"))
     h->ls = atoi(e) != 0 && !h->wave && !h->plane && !(d.flags & MFGPU_COLORED_SCATTER);
-  // apply_batches_x: 3D two-pass default.  Its hanging-node variant spills at the 168-VGPR budget of
-  // three waves per SIMD, so meshes with hanging nodes keep apply_batches unless MFGPU_X=1 asks for it.
+  // apply_batches_x: 3D two-pass default, with and without hanging nodes (MFGPU_X=0: apply_batches)
   h->xk = d.dim == 3 && !h->wave && !h->plane && !h->ls && !(d.flags & MFGPU_COLORED_SCATTER);
-  {
-    const char *e = getenv("MFGPU_X");
-    if (e) h->xk = h->xk && atoi(e) != 0;
-    else if (hn) h->xk = false;
-  }
+  if (const char *e = getenv("MFGPU_X")) h->xk = h->xk && atoi(e) != 0;
   int rc = build_plan(dplan, h->plan);
   if (rc) {
     delete h;

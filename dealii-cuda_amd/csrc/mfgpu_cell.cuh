@@ -56,21 +56,38 @@ __device__ __forceinline__ void lds_store(T *p, int stride, const T (&v)[n]) {
 // One directional pass of resolve_hanging_nodes_shmem on the pencil a thread owns
 // (hanging_nodes.cuh:617-758).  `flag` = the reference's per-thread flag, identical for all
 // points of a pencil along `direction`; type = constr & this_type.
-template <int n, typename T, bool TR>
+template <int n, typename T, bool TR, bool LOWREG = false>
 __device__ __forceinline__ void hn_pencil(const T *__restrict__ W, bool type, T (&v)[n]) {
+  // type:  w = TR ? W[i][q] : W[q][i];  !type: the mirrored entry W[p-i][p-q] / W[p-q][p-i]
+  // (hanging_nodes.cuh:665-681).
   constexpr int p = n - 1;
   T o[n];
+  if (LOWREG) {
+    // apply_batches_x (168-VGPR budget): the mirrored entry sits at n*n - 1 - (index of the unmirrored
+    // one), so ONE load per weight through a signed index, and scheduling barriers keep hipcc from
+    // fetching all n*n weights up front (2 * n * n VGPRs).  This serialises the weight loads of the
+    // flagged pencils and costs apply_batches (256-VGPR budget) 4-6 % on C3, hence opt-in.
+    const int sgn = type ? 1 : -1, base = type ? 0 : n * n - 1;
 #pragma unroll
-  for (int q = 0; q < n; ++q) {
-    T t = 0;
+    for (int q = 0; q < n; ++q) {
+      T t = 0;
 #pragma unroll
-    for (int i = 0; i < n; ++i) {
-      // type:  w = TR ? W[i][q] : W[q][i];  !type: mirrored (hanging_nodes.cuh:665-681)
-      const T w1 = TR ? W[i * n + q] : W[q * n + i];
-      const T w2 = TR ? W[(p - i) * n + (p - q)] : W[(p - q) * n + (p - i)];
-      t = fma(type ? w1 : w2, v[i], t);
+      for (int i = 0; i < n; ++i) t = fma(W[base + sgn * (TR ? i * n + q : q * n + i)], v[i], t);
+      o[q] = t;
+      __builtin_amdgcn_sched_barrier(0);
     }
-    o[q] = t;
+  } else {
+#pragma unroll
+    for (int q = 0; q < n; ++q) {
+      T t = 0;
+#pragma unroll
+      for (int i = 0; i < n; ++i) {
+        const T w1 = TR ? W[i * n + q] : W[q * n + i];
+        const T w2 = TR ? W[(p - i) * n + (p - q)] : W[(p - q) * n + (p - i)];
+        t = fma(type ? w1 : w2, v[i], t);
+      }
+      o[q] = t;
+    }
   }
 #pragma unroll
   for (int q = 0; q < n; ++q) v[q] = o[q];

@@ -53,20 +53,20 @@ __device__ __forceinline__ void cell_pipeline_x(const bool act, const int pa, co
     // resolve_hanging_nodes_shmem<NOTRANSPOSE>: x, then y, then z (hanging_nodes.cuh:767-777)
     bool type;
     if (act) {
-      if (mask && hn_flag3<n, 0>(mask, pa, pb, type)) hn_pencil<n, T, false>(Wl, type, u);
+      if (mask && hn_flag3<n, 0>(mask, pa, pb, type)) hn_pencil<n, T, false, true>(Wl, type, u);
       lds_store<n>(Wc + bx, 1, u);
     }
     __syncthreads();
     // only the pencils on a constrained face or edge change: everybody else skips the round trip
     if (act && mask && hn_flag3<n, 1>(mask, pb, pa, type)) {
       lds_load<n>(Wc + by, n, u);
-      hn_pencil<n, T, false>(Wl, type, u);
+      hn_pencil<n, T, false, true>(Wl, type, u);
       lds_store<n>(Wc + by, n, u);
     }
     __syncthreads();
     if (act && mask && hn_flag3<n, 2>(mask, pa, pb, type)) {
       lds_load<n>(Wc + bz, n2, u);
-      hn_pencil<n, T, false>(Wl, type, u);
+      hn_pencil<n, T, false, true>(Wl, type, u);
       lds_store<n>(Wc + bz, n2, u);
     }
     __syncthreads();
@@ -148,19 +148,19 @@ __device__ __forceinline__ void cell_pipeline_x(const bool act, const int pa, co
     __syncthreads();
     if (act && mask && hn_flag3<n, 1>(mask, pb, pa, type)) {
       lds_load<n>(Rc + by, n, v);
-      hn_pencil<n, T, true>(Wl, type, v);
+      hn_pencil<n, T, true, true>(Wl, type, v);
       lds_store<n>(Rc + by, n, v);
     }
     __syncthreads();
     if (act && mask && hn_flag3<n, 2>(mask, pa, pb, type)) {
       lds_load<n>(Rc + bz, n2, v);
-      hn_pencil<n, T, true>(Wl, type, v);
+      hn_pencil<n, T, true, true>(Wl, type, v);
       lds_store<n>(Rc + bz, n2, v);
     }
     __syncthreads();
     if (act) {
       lds_load<n>(Rc + bx, 1, v);
-      if (mask && hn_flag3<n, 0>(mask, pa, pb, type)) hn_pencil<n, T, true>(Wl, type, v);
+      if (mask && hn_flag3<n, 0>(mask, pa, pb, type)) hn_pencil<n, T, true, true>(Wl, type, v);
     }
   }
   if (act) {

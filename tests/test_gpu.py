@@ -240,10 +240,10 @@ def test_hanging_node_stages_synthetic_masks(dim, p, n, colored, monkeypatch):
     """in-kernel resolve_hanging_nodes (NOTRANSPOSE before evaluate, TRANSPOSE after integrate,
     fee_gpu.cuh:333-335,349-351) against the oracle's emulation for every mask type.  The masks are
     assigned to cells of a conforming mesh: algebraically A = sum_cells P^T C^T K C P either way."""
-    if colored == "x":  # two-pass mode, hanging-node variant of apply_batches_x (3D)
+    if colored == "x":  # two-pass mode with apply_batches instead of the 3D default apply_batches_x
         if dim != 3:
-            pytest.skip("apply_batches_x is a 3D kernel")
-        monkeypatch.setenv("MFGPU_X", "1")
+            pytest.skip("apply_batches_x is a 3D kernel: 2D always runs apply_batches")
+        monkeypatch.setenv("MFGPU_X", "0")
         colored = False
     od = o.uniform_mesh_desc(dim, p, n)
     masks = _all_masks(dim)
@@ -281,14 +281,15 @@ def test_adaptive_mesh_with_hanging_nodes(dim, p, nref, colored):
 
 
 @pytest.mark.parametrize("p,nref", [(4, 4), (2, 4), (3, 5)])
-def test_adaptive_mesh_x_kernel_hanging_node_variant(p, nref, monkeypatch):
-    """apply_batches_x is the 3D default only without hanging nodes (its HN variant spills registers);
-    MFGPU_X=1 selects it for an adaptive mesh as well: same operator."""
-    monkeypatch.setenv("MFGPU_X", "1")
+@pytest.mark.parametrize("xk", ["1", "0"])
+def test_adaptive_mesh_both_cell_loop_kernels(p, nref, xk, monkeypatch):
+    """apply_batches_x is the 3D two-pass default with and without hanging nodes; MFGPU_X=0 selects
+    apply_batches (which also serves 2D and the coloured mode): same operator on an adaptive mesh."""
+    monkeypatch.setenv("MFGPU_X", xk)
     mesh = mf.Mesh.adaptive(3, p, nref)
     od = oracle_desc_from_mesh(mesh, dtype=np.float64)
     op = mf.Operator(mesh.desc, mesh)
-    assert op.kernel_name() == "apply_batches_x"
+    assert op.kernel_name() == ("apply_batches_x" if xk == "1" else "apply_batches")
     rng = np.random.default_rng(5)
     x, y0 = rng.standard_normal(mesh.n_dofs), rng.standard_normal(mesh.n_dofs)
     assert rel(gpu_vmult(op, x), o.vmult(od, x)) <= 1e-12
