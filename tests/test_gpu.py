@@ -338,3 +338,38 @@ def test_bmop_driver_binaries():
     assert out.returncode == 0 and out.stdout.split("\t")[:3] == ["3", "4", str(65 ** 3)]
     out = subprocess.run([os.path.join(b, "bmop-3d-p4-adaptive"), "4", "4"], capture_output=True, text=True, timeout=120)
     assert out.returncode == 0 and out.stdout.split("\t")[:2] == ["3", "4"]
+
+
+@pytest.mark.parametrize("p,n,world", [(4, 7, 2), (2, 9, 3), (4, 12, 4)])
+def test_slab_decomposition_with_the_gpu_operator(p, n, world):
+    """Row (e) on the device, without a second GPU: the HIP operator applied slab by slab (z-slab meshes of
+    the multi-GPU mode, interface planes that are NOT boundary), the interface planes summed as
+    SlabExchange does, against the single-domain oracle.  Two chained applies: the summed planes must be
+    consistent ghost values for the next apply."""
+    from pymfgpu.parallel import slab_ranges
+
+    full = mf.Mesh.uniform(3, p, n)
+    od = oracle_desc_from_mesh(full, dtype=np.float64)
+    fxyz = full.dof_coords()
+    key = {tuple(np.round(c, 9)): i for i, c in enumerate(fxyz)}
+    src_g = np.sin(3 * fxyz[:, 0]) + fxyz[:, 1] ** 2 - np.cos(2 * fxyz[:, 2]) * fxyz[:, 0]
+    slabs = []
+    for zb, ze in slab_ranges(n, world):
+        mesh = mf.Mesh.uniform(3, p, n, slab=(zb, ze))
+        gi = np.array([key[tuple(np.round(c, 9))] for c in mesh.dof_coords()])
+        slabs.append((mesh, mf.Operator(mesh.desc, mesh), gi))
+    con = np.zeros(full.n_dofs, bool)
+    con[od.constrained] = True
+    x = src_g
+    for _ in range(2):
+        acc = np.zeros(full.n_dofs)
+        cnt = np.zeros(full.n_dofs, int)
+        for mesh, op, gi in slabs:
+            y = gpu_vmult(op, x[gi])
+            np.add.at(acc, gi, y)
+            np.add.at(cnt, gi, 1)
+        assert cnt.max() == 2 and cnt.min() == 1           # only interface planes are shared, by two slabs
+        acc[con & (cnt == 2)] *= 0.5                        # identity rows on both sides: not summed
+        ref = o.vmult(od, x)
+        assert rel(acc, ref) <= 1e-12
+        x = acc
