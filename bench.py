@@ -79,6 +79,9 @@ def main():
     ap.add_argument("--batch-cells", type=int, default=0)
     ap.add_argument("--batch-dofs", type=int, default=0)
     ap.add_argument("--colored", action="store_true", help="coloured-scatter mode instead of two-pass")
+    ap.add_argument("--general-jacobian", type=float, default=0.0, metavar="EPS",
+                    help="SURVEY.md 8(f) N3: same mesh, but a full inverse Jacobian per quadrature point "
+                         "(synthetic deformation F = h (I + EPS R), R random in [-1,1]); 1 GPU")
     ap.add_argument("--adaptive", type=int, default=0, metavar="NREF",
                     help="configs[2]: bmop -DADAPTIVE_GRID mesh with hanging nodes instead of the uniform cube (1 GPU)")
     args = ap.parse_args()
@@ -112,7 +115,22 @@ def main():
     mesh.desc.max_dofs_per_batch = args.batch_dofs
     if args.colored:
         mesh.desc.flags |= mf.COLORED_SCATTER
-    op = mf.Operator(mesh.desc, mesh)
+    if args.general_jacobian:
+        if world != 1 or args.adaptive or args.float:
+            raise SystemExit("--general-jacobian: single GPU, uniform connectivity, double")
+        a = mesh.arrays()
+        nc, ndl = mesh.n_cells, (p + 1) ** 3
+        rng = np.random.default_rng(0)
+        h = 1.0 / a["inv_jac"].reshape(nc, 1, 1, 1)
+        F = (np.eye(3) + args.general_jacobian * rng.uniform(-1.0, 1.0, (nc, ndl, 3, 3))) * h
+        jxw = a["JxW"].reshape(nc, ndl) / h.reshape(nc, 1) ** 3 * np.linalg.det(F)
+        gdesc, keep = mf.make_desc(3, p, mesh.n_dofs, a["loc2glob"], jxw, np.linalg.inv(F), None, a["constrained_dofs"],
+                                   a["shape_values"], a["shape_gradients"], quadrature_points=a["quadrature_points"],
+                                   max_cells_per_batch=args.batch_cells, max_dofs_per_batch=args.batch_dofs)
+        del F
+        op = mf.Operator(gdesc, (keep, mesh))
+    else:
+        op = mf.Operator(mesh.desc, mesh)
     stats = op.plan_stats()
     N_loc = mesh.n_dofs
     nd = (p + 1) ** 3
@@ -174,6 +192,8 @@ def main():
     op.profile_enable(False)
     launches = n_v * stats["n_launches"]
     b_alg_loc = algorithmic_bytes(N_loc, mesh.n_cells, nd, s)
+    if args.general_jacobian:  # per quadrature point: the 6 entries of the symmetric a JxW J J^T instead of one scalar
+        b_alg_loc += mesh.n_cells * nd * 5 * s
     achieved = b_alg_loc * n_v / (k_ms * 1e-3) / 1e9  # GB/s, == (B_alg/launch) / (avg launch duration)
     traffic = None
     tj = os.path.join(ROOT, "profiles", "traffic_latest.json")
@@ -182,7 +202,8 @@ def main():
             tr = json.load(open(tj))
             if (tr.get("workload") == f"p{p}_3d_n{n_glob}_{'f32' if args.float else 'f64'}" and world == 1
                     and op.kernel_name() + "<" in tr.get("kernel", "")
-                    and not args.adaptive and not args.colored and not args.batch_cells and not args.batch_dofs):
+                    and not args.adaptive and not args.colored and not args.batch_cells and not args.batch_dofs
+                    and not args.general_jacobian):
                 traffic = tr["hbm_bytes_per_launch"]
         except Exception:
             traffic = None
@@ -202,6 +223,10 @@ def main():
         "data": "synthetic",
         "config": {"workload": (f"bmop: DEGREE_FE={p}, DIMENSION=3, ADAPTIVE_GRID n_ref={args.adaptive}, hanging nodes, "
                                 f"{n_cells_glob} cells, {n_dofs_glob} DoFs") if args.adaptive else
+                               (f"bmop without MATRIX_FREE_UNIFORM_MESH: DEGREE_FE={p}, DIMENSION=3, {n_glob}^3 cells, "
+                                f"{n_dofs_glob} DoFs, full inverse Jacobian per quadrature point (synthetic, eps="
+                                f"{args.general_jacobian}); roofline bytes count the folded 6-entry metric (48 B / point)")
+                               if args.general_jacobian else
                                (f"bmop: DEGREE_FE={p}, DIMENSION=3, MATRIX_FREE_UNIFORM_MESH, hyper_cube(-1,1), "
                                 f"{n_glob}^3 cells, {n_dofs_glob} DoFs, {world} z-slab(s)"),
                    "cells_per_dir": n_glob, "n_dofs": n_dofs_glob, "n_cells": n_cells_glob,

@@ -50,6 +50,7 @@ struct mfgpu_handle {
   bool plane = false;     // experimental plane-per-thread kernel (apply_planes)
   bool ls = false;        // loader / compute specialised cell loop (apply_batches_ls)
   bool xk = false;        // 3D two-pass kernel for three workgroups per CU (apply_batches_x)
+  bool gk = false;        // general-Jacobian kernel (apply_batches_g)
   bool wave = false;      // wave-granular cell phase (apply_batches<..., WAVE = true>)
   // profiling
   bool prof = false;
@@ -113,7 +114,7 @@ int create_typed(mfgpu_handle *h, const mfgpu_desc &d) {
   if ((rc = dev_upload(&h->d_bdofs, P.bdofs.data(), P.bdofs.size() * 4, acct))) return rc;
   if ((rc = dev_upload(&h->d_bflags, P.bflags.data(), P.bflags.size(), acct))) return rc;
   if ((rc = dev_upload(&h->d_lmap, P.lmap.data(), P.lmap.size() * 2, acct))) return rc;
-  if (h->xk) {
+  if (h->xk || h->gk) {
     // x-pencil index runs (n contiguous entries of lmap) padded to whole 32-bit words
     const size_t n = (size_t)P.n, np = (n + 1) & ~(size_t)1, runs = P.lmap.size() / n;
     std::vector<uint16_t> lx(runs * np, 0);
@@ -177,12 +178,15 @@ int create_typed(mfgpu_handle *h, const mfgpu_desc &d) {
     }
   }
   if ((rc = dev_upload(&t_jxw, d.JxW, ncell * nd * sizeof(T), tmp))) { cleanup(); return rc; }
-  if ((rc = dev_upload(&t_j0, d.inv_jac, ncell * sizeof(T), tmp))) { cleanup(); return rc; }
+  const size_t jac_per_cell = h->gk ? nd * (size_t)(P.dim * P.dim) : 1;  // full J^-1 per point, or one scalar per cell
+  if ((rc = dev_upload(&t_j0, d.inv_jac, ncell * jac_per_cell * sizeof(T), tmp))) { cleanup(); return rc; }
   if ((rc = dev_upload(&t_order, P.cell_order.data(), ncell * 4, tmp))) { cleanup(); return rc; }
-  hipError_t e = hipMalloc(&h->d_coef, ncell * nd * sizeof(T));
+  const size_t coef_per_point = h->gk ? 6 : 1;  // symmetric M = a JxW J J^T, or the scalar a J0^2 JxW
+  hipError_t e = hipMalloc(&h->d_coef, ncell * nd * coef_per_point * sizeof(T));
   if (e == hipSuccess) {
-    acct += ncell * nd * sizeof(T);
-    e = fold_launch<T>((T *)h->d_coef, t_coef, t_jxw, t_j0, t_order, (uint32_t)ncell, (uint32_t)nd, nullptr);
+    acct += ncell * nd * coef_per_point * sizeof(T);
+    e = h->gk ? fold_general_launch<T>((T *)h->d_coef, t_coef, t_jxw, t_j0, t_order, (uint32_t)ncell, (uint32_t)nd, nullptr)
+              : fold_launch<T>((T *)h->d_coef, t_coef, t_jxw, t_j0, t_order, (uint32_t)ncell, (uint32_t)nd, nullptr);
   }
   if (e == hipSuccess) e = hipDeviceSynchronize();
   cleanup();
@@ -201,6 +205,24 @@ int create_typed(mfgpu_handle *h, const mfgpu_desc &d) {
     h->max_grid = (uint32_t)(per_cu < 1 ? 1 : per_cu) * (uint32_t)prop.multiProcessorCount;
     if (const char *e = getenv("MFGPU_GRID"))
       if (atoi(e) > 0) h->max_grid = (uint32_t)atoi(e);
+    return 0;
+  }
+  if (h->gk) {
+    ApplyArgs<T> dummy{};
+    dummy.nb_max = P.max_batch_dofs;
+    int per_cu = 0, dev = 0;
+    hipDeviceProp_t prop;
+    HIP_TRY(g_launch<T>(P.n, dummy, nullptr, nullptr, 0, nullptr, true, &h->lds, nullptr));
+    if (h->lds > 160 * 1024) {
+      set_error("batch needs more than 160 KiB of LDS; lower max_dofs_per_batch");
+      return MFGPU_EINVAL;
+    }
+    HIP_TRY(g_launch<T>(P.n, dummy, nullptr, nullptr, 0, nullptr, true, &h->lds, &per_cu));
+    HIP_TRY(hipGetDevice(&dev));
+    HIP_TRY(hipGetDeviceProperties(&prop, dev));
+    h->max_grid = (uint32_t)(per_cu < 1 ? 1 : per_cu) * (uint32_t)prop.multiProcessorCount;
+    if (const char *e2 = getenv("MFGPU_GRID"))
+      if (atoi(e2) > 0) h->max_grid = (uint32_t)atoi(e2);
     return 0;
   }
   if (h->xk) {
@@ -303,7 +325,10 @@ int vmult_typed(mfgpu_handle *h, void *dst, const void *src, hipStream_t st, int
       HIP_TRY(hipEventRecord(h->ev[h->ev_used], st));
     }
     a.batch_end = a.batch0 + nbat;
-    if (h->xk)
+    if (h->gk)
+      HIP_TRY(g_launch<T>(P.n, a, h->S.data(), h->Dt.data(), nbat < h->max_grid ? nbat : h->max_grid, st, false, nullptr,
+                          nullptr));
+    else if (h->xk)
       HIP_TRY(x_launch<T>(P.n, a, h->S.data(), h->Dt.data(), h->hn, nbat < h->max_grid ? nbat : h->max_grid, st,
                           false, nullptr, nullptr));
     else if (h->ls)
@@ -406,9 +431,10 @@ int mfgpu_create(const mfgpu_desc *desc, mfgpu_handle **out) {
     set_error("number_type must be MFGPU_F64 or MFGPU_F32");
     return MFGPU_EINVAL;
   }
-  if (!(d.flags & MFGPU_UNIFORM_J0)) {
-    set_error("only the MFGPU_UNIFORM_J0 geometry path (one scalar inverse Jacobian per cell, "
-              "reference MATRIX_FREE_UNIFORM_MESH) is implemented");
+  const bool general = !(d.flags & MFGPU_UNIFORM_J0);
+  if (general && (d.dim != 3 || (d.flags & MFGPU_HANGING_NODES) || (d.flags & MFGPU_COLORED_SCATTER))) {
+    set_error("the general-Jacobian path (no MFGPU_UNIFORM_J0) is implemented for 3D conforming meshes in "
+              "two-pass scatter mode only");
     return MFGPU_EUNSUPPORTED;
   }
   if (!d.JxW || !d.inv_jac || !d.shape_values || !d.shape_gradients ||
@@ -442,6 +468,10 @@ int mfgpu_create(const mfgpu_desc *desc, mfgpu_handle **out) {
   // apply_batches_x: 3D two-pass default, with and without hanging nodes (MFGPU_X=0: apply_batches)
   h->xk = d.dim == 3 && !h->wave && !h->plane && !h->ls && !(d.flags & MFGPU_COLORED_SCATTER);
   if (const char *e = getenv("MFGPU_X")) h->xk = h->xk && atoi(e) != 0;
+  if (general) {  // apply_batches_g is the only kernel of the general-Jacobian path
+    h->gk = true;
+    h->xk = h->wave = h->plane = h->ls = false;
+  }
   int rc = build_plan(dplan, h->plan);
   if (rc) {
     delete h;
@@ -554,7 +584,7 @@ int mfgpu_plan_stats(const mfgpu_handle *h, uint64_t s[8]) {
 
 const char *mfgpu_kernel_name(const mfgpu_handle *h) {
   if (!h) return "";
-  return h->xk ? "apply_batches_x" : h->ls ? "apply_batches_ls" : h->plane ? "apply_planes" : "apply_batches";
+  return h->gk ? "apply_batches_g" : h->xk ? "apply_batches_x" : h->ls ? "apply_batches_ls" : h->plane ? "apply_planes" : "apply_batches";
 }
 
 int mfgpu_profile_enable(mfgpu_handle *h, int on) {
@@ -607,6 +637,10 @@ int mfgpu_compute_inverse_diagonal(mfgpu_handle *h, void *inv_diag, void *stream
   if (!h || !inv_diag) {
     set_error("null argument");
     return MFGPU_EINVAL;
+  }
+  if (h->gk) {
+    set_error("compute_inverse_diagonal is not implemented for the general-Jacobian path yet");
+    return MFGPU_EUNSUPPORTED;
   }
   return h->number_type == MFGPU_F64 ? inverse_diagonal_typed<double>(h, inv_diag, (hipStream_t)stream)
                                      : inverse_diagonal_typed<float>(h, inv_diag, (hipStream_t)stream);

@@ -16,7 +16,7 @@ struct ApplyArgs {
   const uint8_t *bflags;
   const uint16_t *lmap;
   const uint16_t *lmapx;  // apply_batches_x: x-pencil index runs padded to 32-bit words, or nullptr
-  const T *coef;          // folded a*J0^2*JxW, plan cell order
+  const T *coef;          // folded a*J0^2*JxW (apply_batches_g: the 6 entries of a*JxW*J*J^T), plan cell order
   const uint32_t *cmask;  // plan cell order, or nullptr
   const T *hn_weights;    // [n*n] W[i*n+j] (device), or nullptr
   const uint32_t *batch_nint;  // two-pass mode: interior dofs per batch
@@ -63,6 +63,13 @@ hipError_t plane_launch(int n, const ApplyArgs<T> &a, const double *S, const dou
 template <typename T>
 hipError_t x_launch(int n, const ApplyArgs<T> &a, const double *S, const double *Dt, bool hn, uint32_t grid,
                     hipStream_t st, bool configure_only, size_t *lds_out, int *occupancy);
+// general-Jacobian cell loop (mfgpu_kernels_g.hip; 3D, two-pass mode, conforming meshes) and its setup fold
+template <typename T>
+hipError_t g_launch(int n, const ApplyArgs<T> &a, const double *S, const double *Dt, uint32_t grid, hipStream_t st,
+                    bool configure_only, size_t *lds_out, int *occupancy);
+template <typename T>
+hipError_t fold_general_launch(T *M, const T *coef, const T *jxw, const T *jinv, const uint32_t *order,
+                               uint32_t n_cells, uint32_t nd, hipStream_t st);
 // loader / compute specialised cell loop (mfgpu_kernels_ls.hip; two-pass mode)
 template <typename T>
 hipError_t ls_launch(int dim, int n, const ApplyArgs<T> &a, const double *S, const double *Dt, bool hn,

@@ -233,10 +233,14 @@ def make_desc(dim, degree, n_dofs, loc2glob, JxW, inv_jac, coefficient, constrai
 
     d = Desc()
     d.dim, d.degree, d.number_type = dim, degree, number_type
-    d.flags = UNIFORM_J0 | (HANGING_NODES if constraint_mask is not None else 0) | (COLORED_SCATTER if colored else 0)
     l2g = np.ascontiguousarray(loc2glob, dtype=np.uint32)
     d.n_dofs = int(n_dofs)
     d.n_cells = l2g.size // ((degree + 1) ** dim)
+    # one scalar J^-1 per cell (reference MATRIX_FREE_UNIFORM_MESH), or J^-1[dim][dim] per quadrature point
+    uniform = np.asarray(inv_jac).size == d.n_cells
+    assert uniform or np.asarray(inv_jac).size == l2g.size * dim * dim
+    d.flags = ((UNIFORM_J0 if uniform else 0) | (HANGING_NODES if constraint_mask is not None else 0)
+               | (COLORED_SCATTER if colored else 0))
     d.loc2glob = ptr(l2g, np.uint32)
     d.constraint_mask = ptr(constraint_mask, np.uint32)
     d.JxW = ptr(JxW, dt)

@@ -40,7 +40,11 @@ extern "C" {
 /* flags */
 #define MFGPU_UNIFORM_J0 (1u << 0)    /* inv_jac holds ONE scalar J^-1[0][0] per cell
                                          (MATRIX_FREE_UNIFORM_MESH, matrix_free_gpu.cu:332-334,
-                                         fee_gpu.cuh:225-241)                                   */
+                                         fee_gpu.cuh:225-241).  Without it: the reference's default
+                                         geometry path, a full J^-1 per quadrature point (fee_gpu.cuh:
+                                         235-241,275-281) -- implemented for dim = 3,
+                                         conforming meshes, two-pass scatter mode; other combinations
+                                         return MFGPU_EUNSUPPORTED                                  */
 #define MFGPU_HANGING_NODES (1u << 1) /* constraint_mask is given (MATRIX_FREE_HANGING_NODES,
                                          fee_gpu.cuh:333-335,349-351)                           */
 

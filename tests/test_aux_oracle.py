@@ -44,3 +44,17 @@ def test_inverse_diagonal_with_hanging_node_masks_follows_the_reference_quirk():
     assert np.abs(1.0 / inv[g] - true_diag[g]).max() > 1e-8      # the quirk is visible on that cell
     other = np.setdiff1d(np.arange(od.n_dofs), g)
     np.testing.assert_allclose(1.0 / inv[other], true_diag[other], rtol=1e-12)
+
+
+@pytest.mark.parametrize("p,n", [(1, 3), (2, 2), (3, 2)])
+def test_general_jacobian_oracle_against_assembled_matrix(p, n):
+    """SURVEY.md 8f N3 on the CPU: the oracle's general-geometry branch (fee_gpu.cuh:235-241,275-281 restated
+    in cell_apply) against the independently assembled matrix (physical gradients, test_laplace_op.cu:50-120)."""
+    from util import deformed_oracle_desc
+
+    od = deformed_oracle_desc(p, n)
+    assert not od.uniform_j0
+    x = np.random.default_rng(1).standard_normal(od.n_dofs)
+    y = o.vmult(od, x)
+    ref = o.assemble(od) @ x
+    assert np.linalg.norm(y - ref) <= 1e-13 * np.linalg.norm(ref)

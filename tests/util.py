@@ -75,3 +75,20 @@ def emulate_plan_vmult(od: o.Desc, plan: "mf.Plan", src, dst_in=None, twopass=Fa
         s = src[g] if (oo >> 31) else 0.0
         dst[g] = (dst[g] if add else 0.0) + s
     return dst
+
+
+def deformed_oracle_desc(p, n, eps=0.12, seed=0, dtype=np.float64):
+    """3D oracle Desc with GENERAL geometry data: the uniform cube's connectivity with a
+    synthetic reference->physical Jacobian F = h (I + eps R) per quadrature point (R random in [-1,1]), i.e.
+    inv_jac = F^-1 [cell][q][d1][d2] and JxW = det(F) w_q.  The operator is defined by these arrays alone
+    (fee_gpu.cuh:235-241,275-281), so any smooth or rough field with det F > 0 exercises the code path."""
+    od = o.uniform_mesh_desc(3, p, n, dtype=dtype)
+    nc, nd = od.n_cells, od.nd
+    h = 2.0 / n
+    rng = np.random.default_rng(seed)
+    F = h * (np.eye(3) + eps * rng.uniform(-1.0, 1.0, (nc, nd, 3, 3)))
+    det = np.linalg.det(F)
+    assert det.min() > 0
+    jxw = od.JxW.astype(np.float64).reshape(nc, nd) / h ** 3 * det
+    return o.Desc(3, p, od.n_dofs, od.loc2glob, jxw, np.linalg.inv(F), od.coefficient, od.constrained, None, dtype,
+                  od.shape_values, od.shape_gradients)
