@@ -363,12 +363,12 @@ namespace {
 template <typename T>
 int inverse_diagonal_typed(mfgpu_handle *h, void *diag, hipStream_t st) {
   const Plan &P = h->plan;
-  if (!h->d_tab2) {  // squared 1D tables [S.^2 | G.^2], T[2][n*n]
+  if (!h->d_tab2) {  // 1D tables T[2][n*n]: squared [S.^2 | G.^2], or plain [S | G] for the general-geometry path
     const int nn = h->n * h->n;
     std::vector<T> t2(2 * (size_t)nn);
     for (int i = 0; i < nn; ++i) {
-      t2[i] = (T)(h->sv[i] * h->sv[i]);
-      t2[nn + i] = (T)(h->sg[i] * h->sg[i]);
+      t2[i] = (T)(h->gk ? h->sv[i] : h->sv[i] * h->sv[i]);
+      t2[nn + i] = (T)(h->gk ? h->sg[i] : h->sg[i] * h->sg[i]);
     }
     int rc = dev_upload(&h->d_tab2, t2.data(), t2.size() * sizeof(T), h->device_bytes);
     if (rc) return rc;
@@ -376,9 +376,14 @@ int inverse_diagonal_typed(mfgpu_handle *h, void *diag, hipStream_t st) {
   // inv_diag.reinit(m()): zero  (laplace_operator_gpu.h:407)
   HIP_TRY(fill_launch<T>((T *)diag, P.n_dofs, T(0), st));
   // data.cell_loop(inv_diag, diag_loc_op)  (:409-410)
-  HIP_TRY(diag_launch<T>(P.dim, P.n, (T *)diag, (uint32_t)(P.batch_cell_off.size() - 1), h->d_batch_cell_off,
-                         h->d_batch_dof_off, h->d_bdofs, h->d_lmap, (const T *)h->d_coef, h->d_cmask,
-                         (const T *)h->d_hnw, (const T *)h->d_tab2, st));
+  if (h->gk)
+    HIP_TRY(diag_general_launch<T>(P.n, (T *)diag, (uint32_t)(P.batch_cell_off.size() - 1), h->d_batch_cell_off,
+                                   h->d_batch_dof_off, h->d_bdofs, h->d_lmap, (const T *)h->d_coef,
+                                   (const T *)h->d_tab2, st));
+  else
+    HIP_TRY(diag_launch<T>(P.dim, P.n, (T *)diag, (uint32_t)(P.batch_cell_off.size() - 1), h->d_batch_cell_off,
+                           h->d_batch_dof_off, h->d_bdofs, h->d_lmap, (const T *)h->d_coef, h->d_cmask,
+                           (const T *)h->d_hnw, (const T *)h->d_tab2, st));
   // constraint_handler.set_constrained_values(inv_diag, 1.0)  (:412)
   HIP_TRY(set_values_launch<T>((T *)diag, h->d_constrained, h->n_constrained, T(1), st));
   // inv_diag.invert()  (:414)
@@ -637,10 +642,6 @@ int mfgpu_compute_inverse_diagonal(mfgpu_handle *h, void *inv_diag, void *stream
   if (!h || !inv_diag) {
     set_error("null argument");
     return MFGPU_EINVAL;
-  }
-  if (h->gk) {
-    set_error("compute_inverse_diagonal is not implemented for the general-Jacobian path yet");
-    return MFGPU_EUNSUPPORTED;
   }
   return h->number_type == MFGPU_F64 ? inverse_diagonal_typed<double>(h, inv_diag, (hipStream_t)stream)
                                      : inverse_diagonal_typed<float>(h, inv_diag, (hipStream_t)stream);

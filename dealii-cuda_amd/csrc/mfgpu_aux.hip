@@ -110,6 +110,65 @@ diag_kernel(T *diag, const uint32_t *batch_cell_off, const uint32_t *batch_dof_o
   }
 }
 
+// General-geometry variant (no MFGPU_UNIFORM_J0, 3D): K_ii = sum_q ghat_i(q)^T M(q) ghat_i(q) with the folded
+// symmetric metric M = a JxW J J^T of apply_batches_g ([cell][entry][q], entries 00 01 02 11 12 22) and
+// ghat_i(q) = (G[ix][qx] S[iy][qy] S[iz][qz], S G S, S S G).  tab2 here holds the UNSQUARED tables [S | G].
+template <int n, typename T>
+__global__ void __launch_bounds__(256)
+diag_general_kernel(T *diag, const uint32_t *batch_cell_off, const uint32_t *batch_dof_off, const uint32_t *bdofs,
+                    const uint16_t *lmap, const T *metric, const T *tab) {
+  constexpr int n2 = n * n, nd = n2 * n;
+  __shared__ T S[n2], G[n2], m[6 * nd];
+  const int tid = threadIdx.x;
+  for (int t = tid; t < n2; t += 256) {
+    S[t] = tab[t];
+    G[t] = tab[n2 + t];
+  }
+  const uint32_t b = blockIdx.x;
+  const uint32_t c0 = batch_cell_off[b], c1 = batch_cell_off[b + 1], d0 = batch_dof_off[b];
+  for (uint32_t c = c0; c < c1; ++c) {
+    __syncthreads();
+    for (int i = tid; i < 6 * nd; i += 256) m[i] = metric[(size_t)c * (6 * nd) + i];
+    __syncthreads();
+    for (int i = tid; i < nd; i += 256) {
+      const int ix = i % n, iy = (i / n) % n, iz = i / n2;
+      T sum = T(0);
+      for (int qz = 0; qz < n; ++qz)
+        for (int qy = 0; qy < n; ++qy) {
+          const T syz = S[iy * n + qy] * S[iz * n + qz];
+          const T gy0 = G[iy * n + qy] * S[iz * n + qz];
+          const T gz0 = S[iy * n + qy] * G[iz * n + qz];
+          for (int qx = 0; qx < n; ++qx) {
+            const int q = qx + n * qy + n2 * qz;
+            const T gx = G[ix * n + qx] * syz, gy = S[ix * n + qx] * gy0, gz = S[ix * n + qx] * gz0;
+            sum += m[q] * gx * gx + m[3 * nd + q] * gy * gy + m[5 * nd + q] * gz * gz +
+                   T(2) * (m[nd + q] * gx * gy + m[2 * nd + q] * gx * gz + m[4 * nd + q] * gy * gz);
+          }
+        }
+      const uint32_t g = bdofs[d0 + lmap[(size_t)c * nd + i]];
+      if (!(g >> 31)) atomicAdd(diag + g, sum);
+    }
+  }
+}
+
+template <typename T>
+hipError_t diag_general_launch(int n, T *diag, uint32_t n_batches, const uint32_t *batch_cell_off,
+                               const uint32_t *batch_dof_off, const uint32_t *bdofs, const uint16_t *lmap,
+                               const T *metric, const T *tab, hipStream_t st) {
+  if (n_batches == 0) return hipSuccess;
+#define DG_CASE(N)                                                                                           \
+  case N:                                                                                                    \
+    hipLaunchKernelGGL((diag_general_kernel<N, T>), dim3(n_batches), dim3(256), 0, st, diag, batch_cell_off, \
+                       batch_dof_off, bdofs, lmap, metric, tab);                                             \
+    break;
+  switch (n) {
+    DG_CASE(2) DG_CASE(3) DG_CASE(4) DG_CASE(5) DG_CASE(6) DG_CASE(7)
+    default: return hipErrorInvalidValue;
+  }
+#undef DG_CASE
+  return hipGetLastError();
+}
+
 template <typename T>
 __global__ void set_values_kernel(T *v, const uint32_t *idx, uint32_t n, T value) {
   const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
@@ -264,6 +323,8 @@ hipError_t vec_reduce_launch(int op, T *v, const T *x, const T *w, T a, size_t n
 #define INST(T)                                                                                              \
   template hipError_t diag_launch<T>(int, int, T *, uint32_t, const uint32_t *, const uint32_t *, const uint32_t *, \
                                      const uint16_t *, const T *, const uint32_t *, const T *, const T *, hipStream_t); \
+  template hipError_t diag_general_launch<T>(int, T *, uint32_t, const uint32_t *, const uint32_t *, const uint32_t *, \
+                                             const uint16_t *, const T *, const T *, hipStream_t);           \
   template hipError_t set_values_launch<T>(T *, const uint32_t *, uint32_t, T, hipStream_t);                  \
   template hipError_t vec_map_launch<T>(int, T *, const T *, T, T, size_t, hipStream_t);                      \
   template hipError_t vec_reduce_launch<T>(int, T *, const T *, const T *, T, size_t, hipStream_t, double *);

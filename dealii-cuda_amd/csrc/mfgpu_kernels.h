@@ -90,6 +90,10 @@ hipError_t diag_launch(int dim, int n, T *diag, uint32_t n_batches, const uint32
                        const uint32_t *batch_dof_off, const uint32_t *bdofs, const uint16_t *lmap, const T *coef,
                        const uint32_t *cmask, const T *hn_weights, const T *tab2, hipStream_t st);
 template <typename T>
+hipError_t diag_general_launch(int n, T *diag, uint32_t n_batches, const uint32_t *batch_cell_off,
+                               const uint32_t *batch_dof_off, const uint32_t *bdofs, const uint16_t *lmap,
+                               const T *metric, const T *tab, hipStream_t st);
+template <typename T>
 hipError_t set_values_launch(T *v, const uint32_t *idx, uint32_t n, T value, hipStream_t st);
 // op: 0 sadd (v = s v + a w), 1 equ (v = a w), 2 scale (v *= w), 3 divide (v /= w), 4 invert, 5 mul (v *= a)
 template <typename T>

@@ -58,3 +58,10 @@ def test_general_jacobian_oracle_against_assembled_matrix(p, n):
     y = o.vmult(od, x)
     ref = o.assemble(od) @ x
     assert np.linalg.norm(y - ref) <= 1e-13 * np.linalg.norm(ref)
+
+
+def test_inverse_diagonal_general_geometry_equals_assembled_diagonal():
+    from util import deformed_oracle_desc
+
+    od = deformed_oracle_desc(2, 2)
+    np.testing.assert_allclose(1.0 / o.compute_inverse_diagonal(od), o.assemble(od).diagonal(), rtol=1e-12)

@@ -63,7 +63,45 @@ def test_general_jacobian_unsupported_combinations_are_loud():
     desc, keep = desc_from_oracle(od, colored=True)
     with pytest.raises(mf.MfgpuError):
         mf.Operator(desc, keep)
+
+
+@pytest.mark.parametrize("p,n", [(1, 4), (2, 3), (4, 3), (5, 2)])
+def test_general_jacobian_inverse_diagonal_and_pcg(p, n):
+    """N1 on the N3 path: inverse diagonal against the oracle and the assembled matrix, then the Jacobi-PCG of
+    test_gpu_aux on the deformed geometry against a sparse direct solve."""
+    import scipy.sparse.linalg as spla
+
+    od = deformed_oracle_desc(p, n, seed=5)
     desc, keep = desc_from_oracle(od)
     op = mf.Operator(desc, keep)
-    with pytest.raises(mf.MfgpuError):
-        op.compute_inverse_diagonal(mf.DeviceVector(od.n_dofs))
+    N = od.n_dofs
+    dinv = mf.DeviceVector(N)
+    op.compute_inverse_diagonal(dinv)
+    mf.synchronize()
+    np.testing.assert_allclose(dinv.to_host(), o.compute_inverse_diagonal(od), rtol=1e-12)
+    A = o.assemble(od).tocsc()
+    np.testing.assert_allclose(1.0 / dinv.to_host(), A.diagonal(), rtol=1e-11)
+    b_host = np.random.default_rng(1).standard_normal(N)
+    b_host[od.constrained] = 0.0
+    x_ref = spla.spsolve(A, b_host)
+    b, x, r, z, pv, q = (mf.DeviceVector(N) for _ in range(6))
+    b.from_host(b_host)
+    r.equ(1.0, b)
+    z.equ(1.0, r)
+    z.scale(dinv)
+    pv.equ(1.0, z)
+    rz, r0 = r.dot(z), r.l2_norm()
+    for its in range(1, 3000):
+        op.vmult(q, pv)
+        alpha = rz / pv.dot(q)
+        x.add(alpha, pv)
+        r.add(-alpha, q)
+        if r.l2_norm() <= 1e-12 * r0:
+            break
+        z.equ(1.0, r)
+        z.scale(dinv)
+        rz_new = r.dot(z)
+        pv.sadd(rz_new / rz, 1.0, z)
+        rz = rz_new
+    assert its < 2999
+    assert np.linalg.norm(x.to_host() - x_ref) <= 1e-8 * np.linalg.norm(x_ref)
