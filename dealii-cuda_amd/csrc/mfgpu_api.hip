@@ -212,12 +212,12 @@ int create_typed(mfgpu_handle *h, const mfgpu_desc &d) {
     dummy.nb_max = P.max_batch_dofs;
     int per_cu = 0, dev = 0;
     hipDeviceProp_t prop;
-    HIP_TRY(g_launch<T>(P.n, dummy, nullptr, nullptr, 0, nullptr, true, &h->lds, nullptr));
+    HIP_TRY(g_launch<T>(P.n, dummy, nullptr, nullptr, h->hn, 0, nullptr, true, &h->lds, nullptr));
     if (h->lds > 160 * 1024) {
       set_error("batch needs more than 160 KiB of LDS; lower max_dofs_per_batch");
       return MFGPU_EINVAL;
     }
-    HIP_TRY(g_launch<T>(P.n, dummy, nullptr, nullptr, 0, nullptr, true, &h->lds, &per_cu));
+    HIP_TRY(g_launch<T>(P.n, dummy, nullptr, nullptr, h->hn, 0, nullptr, true, &h->lds, &per_cu));
     HIP_TRY(hipGetDevice(&dev));
     HIP_TRY(hipGetDeviceProperties(&prop, dev));
     h->max_grid = (uint32_t)(per_cu < 1 ? 1 : per_cu) * (uint32_t)prop.multiProcessorCount;
@@ -326,8 +326,8 @@ int vmult_typed(mfgpu_handle *h, void *dst, const void *src, hipStream_t st, int
     }
     a.batch_end = a.batch0 + nbat;
     if (h->gk)
-      HIP_TRY(g_launch<T>(P.n, a, h->S.data(), h->Dt.data(), nbat < h->max_grid ? nbat : h->max_grid, st, false, nullptr,
-                          nullptr));
+      HIP_TRY(g_launch<T>(P.n, a, h->S.data(), h->Dt.data(), h->hn, nbat < h->max_grid ? nbat : h->max_grid, st, false,
+                          nullptr, nullptr));
     else if (h->xk)
       HIP_TRY(x_launch<T>(P.n, a, h->S.data(), h->Dt.data(), h->hn, nbat < h->max_grid ? nbat : h->max_grid, st,
                           false, nullptr, nullptr));
@@ -378,8 +378,8 @@ int inverse_diagonal_typed(mfgpu_handle *h, void *diag, hipStream_t st) {
   // data.cell_loop(inv_diag, diag_loc_op)  (:409-410)
   if (h->gk)
     HIP_TRY(diag_general_launch<T>(P.n, (T *)diag, (uint32_t)(P.batch_cell_off.size() - 1), h->d_batch_cell_off,
-                                   h->d_batch_dof_off, h->d_bdofs, h->d_lmap, (const T *)h->d_coef,
-                                   (const T *)h->d_tab2, st));
+                                   h->d_batch_dof_off, h->d_bdofs, h->d_lmap, (const T *)h->d_coef, h->d_cmask,
+                                   (const T *)h->d_hnw, (const T *)h->d_tab2, st));
   else
     HIP_TRY(diag_launch<T>(P.dim, P.n, (T *)diag, (uint32_t)(P.batch_cell_off.size() - 1), h->d_batch_cell_off,
                            h->d_batch_dof_off, h->d_bdofs, h->d_lmap, (const T *)h->d_coef, h->d_cmask,
@@ -437,9 +437,9 @@ int mfgpu_create(const mfgpu_desc *desc, mfgpu_handle **out) {
     return MFGPU_EINVAL;
   }
   const bool general = !(d.flags & MFGPU_UNIFORM_J0);
-  if (general && (d.dim != 3 || (d.flags & MFGPU_HANGING_NODES) || (d.flags & MFGPU_COLORED_SCATTER))) {
-    set_error("the general-Jacobian path (no MFGPU_UNIFORM_J0) is implemented for 3D conforming meshes in "
-              "two-pass scatter mode only");
+  if (general && (d.dim != 3 || (d.flags & MFGPU_COLORED_SCATTER))) {
+    set_error("the general-Jacobian path (no MFGPU_UNIFORM_J0) is implemented for 3D meshes in two-pass "
+              "scatter mode only");
     return MFGPU_EUNSUPPORTED;
   }
   if (!d.JxW || !d.inv_jac || !d.shape_values || !d.shape_gradients ||

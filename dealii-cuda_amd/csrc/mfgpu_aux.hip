@@ -14,6 +14,50 @@
 
 namespace mfgpu {
 
+// resolve_hanging_nodes_shmem<TRANSPOSE> on ONE cell's local vector in LDS (x, then y, then z;
+// hanging_nodes.cuh:767-777); mask is uniform over the workgroup; ends with a barrier when mask != 0
+template <int dim, int n, typename T>
+__device__ __forceinline__ void hn_transpose_local(T *loc, const T *Wl, unsigned mask, int tid) {
+  constexpr int n2 = n * n, nd = (dim == 3) ? n2 * n : n2, P = nd / n;
+  if (!mask) return;
+  T v[n];
+  bool type;
+  const int pa = (dim == 3) ? tid % n : tid, pb = (dim == 3) ? tid / n : 0;
+  const bool on = tid < P;
+  if (dim == 3) {
+    if (on && hn_flag3<n, 0>(mask, pa, pb, type)) {
+      lds_load<n>(loc + n * pa + n2 * pb, 1, v);
+      hn_pencil<n, T, true>(Wl, type, v);
+      lds_store<n>(loc + n * pa + n2 * pb, 1, v);
+    }
+    __syncthreads();
+    if (on && hn_flag3<n, 1>(mask, pb, pa, type)) {
+      lds_load<n>(loc + pa + n2 * pb, n, v);
+      hn_pencil<n, T, true>(Wl, type, v);
+      lds_store<n>(loc + pa + n2 * pb, n, v);
+    }
+    __syncthreads();
+    if (on && hn_flag3<n, 2>(mask, pa, pb, type)) {
+      lds_load<n>(loc + pa + n * pb, n2, v);
+      hn_pencil<n, T, true>(Wl, type, v);
+      lds_store<n>(loc + pa + n * pb, n2, v);
+    }
+  } else {
+    if (on && hn_flag2<n, 0>(mask, pa, type)) {
+      lds_load<n>(loc + n * pa, 1, v);
+      hn_pencil<n, T, true>(Wl, type, v);
+      lds_store<n>(loc + n * pa, 1, v);
+    }
+    __syncthreads();
+    if (on && hn_flag2<n, 1>(mask, pa, type)) {
+      lds_load<n>(loc + pa, n, v);
+      hn_pencil<n, T, true>(Wl, type, v);
+      lds_store<n>(loc + pa, n, v);
+    }
+  }
+  __syncthreads();
+}
+
 // ---------------------------------------------------------------------------------------------
 // N1: diagonal
 // ---------------------------------------------------------------------------------------------
@@ -31,7 +75,7 @@ template <int dim, int n, typename T>
 __global__ void __launch_bounds__(256)
 diag_kernel(T *diag, const uint32_t *batch_cell_off, const uint32_t *batch_dof_off, const uint32_t *bdofs,
             const uint16_t *lmap, const T *coef, const uint32_t *cmask, const T *hn_weights, const T *tab2) {
-  constexpr int n2 = n * n, nd = (dim == 3) ? n2 * n : n2, P = nd / n;
+  constexpr int n2 = n * n, nd = (dim == 3) ? n2 * n : n2;
   __shared__ T S2[n2], G2[n2], Wl[n2], loc[nd], cf[nd];
   const int tid = threadIdx.x;
   for (int t = tid; t < n2; t += 256) {
@@ -64,45 +108,7 @@ diag_kernel(T *diag, const uint32_t *batch_cell_off, const uint32_t *batch_dof_o
       loc[i] = sum;
     }
     __syncthreads();
-    const unsigned mask = cmask ? cmask[c] : 0u;
-    if (mask) {  // uniform: resolve_hanging_nodes_shmem<TRANSPOSE>, x then y then z (hanging_nodes.cuh:767-777)
-      T v[n];
-      bool type;
-      const int pa = (dim == 3) ? tid % n : tid, pb = (dim == 3) ? tid / n : 0;
-      const bool on = tid < P;
-      if (dim == 3) {
-        if (on && hn_flag3<n, 0>(mask, pa, pb, type)) {
-          lds_load<n>(loc + n * pa + n2 * pb, 1, v);
-          hn_pencil<n, T, true>(Wl, type, v);
-          lds_store<n>(loc + n * pa + n2 * pb, 1, v);
-        }
-        __syncthreads();
-        if (on && hn_flag3<n, 1>(mask, pb, pa, type)) {
-          lds_load<n>(loc + pa + n2 * pb, n, v);
-          hn_pencil<n, T, true>(Wl, type, v);
-          lds_store<n>(loc + pa + n2 * pb, n, v);
-        }
-        __syncthreads();
-        if (on && hn_flag3<n, 2>(mask, pa, pb, type)) {
-          lds_load<n>(loc + pa + n * pb, n2, v);
-          hn_pencil<n, T, true>(Wl, type, v);
-          lds_store<n>(loc + pa + n * pb, n2, v);
-        }
-      } else {
-        if (on && hn_flag2<n, 0>(mask, pa, type)) {
-          lds_load<n>(loc + n * pa, 1, v);
-          hn_pencil<n, T, true>(Wl, type, v);
-          lds_store<n>(loc + n * pa, 1, v);
-        }
-        __syncthreads();
-        if (on && hn_flag2<n, 1>(mask, pa, type)) {
-          lds_load<n>(loc + pa, n, v);
-          hn_pencil<n, T, true>(Wl, type, v);
-          lds_store<n>(loc + pa, n, v);
-        }
-      }
-      __syncthreads();
-    }
+    hn_transpose_local<dim, n, T>(loc, Wl, cmask ? cmask[c] : 0u, tid);
     for (int i = tid; i < nd; i += 256) {
       const uint32_t g = bdofs[d0 + lmap[(size_t)c * nd + i]];
       if (!(g >> 31)) atomicAdd(diag + g, loc[i]);  // constrained rows are set by set_values_kernel
@@ -116,13 +122,14 @@ diag_kernel(T *diag, const uint32_t *batch_cell_off, const uint32_t *batch_dof_o
 template <int n, typename T>
 __global__ void __launch_bounds__(256)
 diag_general_kernel(T *diag, const uint32_t *batch_cell_off, const uint32_t *batch_dof_off, const uint32_t *bdofs,
-                    const uint16_t *lmap, const T *metric, const T *tab) {
+                    const uint16_t *lmap, const T *metric, const uint32_t *cmask, const T *hn_weights, const T *tab) {
   constexpr int n2 = n * n, nd = n2 * n;
-  __shared__ T S[n2], G[n2], m[6 * nd];
+  __shared__ T S[n2], G[n2], Wl[n2], loc[nd], m[6 * nd];
   const int tid = threadIdx.x;
   for (int t = tid; t < n2; t += 256) {
     S[t] = tab[t];
     G[t] = tab[n2 + t];
+    Wl[t] = hn_weights ? hn_weights[t] : T(0);
   }
   const uint32_t b = blockIdx.x;
   const uint32_t c0 = batch_cell_off[b], c1 = batch_cell_off[b + 1], d0 = batch_dof_off[b];
@@ -145,8 +152,13 @@ diag_general_kernel(T *diag, const uint32_t *batch_cell_off, const uint32_t *bat
                    T(2) * (m[nd + q] * gx * gy + m[2 * nd + q] * gx * gz + m[4 * nd + q] * gy * gz);
           }
         }
+      loc[i] = sum;
+    }
+    __syncthreads();
+    hn_transpose_local<3, n, T>(loc, Wl, cmask ? cmask[c] : 0u, tid);
+    for (int i = tid; i < nd; i += 256) {
       const uint32_t g = bdofs[d0 + lmap[(size_t)c * nd + i]];
-      if (!(g >> 31)) atomicAdd(diag + g, sum);
+      if (!(g >> 31)) atomicAdd(diag + g, loc[i]);
     }
   }
 }
@@ -154,12 +166,13 @@ diag_general_kernel(T *diag, const uint32_t *batch_cell_off, const uint32_t *bat
 template <typename T>
 hipError_t diag_general_launch(int n, T *diag, uint32_t n_batches, const uint32_t *batch_cell_off,
                                const uint32_t *batch_dof_off, const uint32_t *bdofs, const uint16_t *lmap,
-                               const T *metric, const T *tab, hipStream_t st) {
+                               const T *metric, const uint32_t *cmask, const T *hn_weights, const T *tab,
+                               hipStream_t st) {
   if (n_batches == 0) return hipSuccess;
 #define DG_CASE(N)                                                                                           \
   case N:                                                                                                    \
     hipLaunchKernelGGL((diag_general_kernel<N, T>), dim3(n_batches), dim3(256), 0, st, diag, batch_cell_off, \
-                       batch_dof_off, bdofs, lmap, metric, tab);                                             \
+                       batch_dof_off, bdofs, lmap, metric, cmask, hn_weights, tab);                          \
     break;
   switch (n) {
     DG_CASE(2) DG_CASE(3) DG_CASE(4) DG_CASE(5) DG_CASE(6) DG_CASE(7)
@@ -324,7 +337,8 @@ hipError_t vec_reduce_launch(int op, T *v, const T *x, const T *w, T a, size_t n
   template hipError_t diag_launch<T>(int, int, T *, uint32_t, const uint32_t *, const uint32_t *, const uint32_t *, \
                                      const uint16_t *, const T *, const uint32_t *, const T *, const T *, hipStream_t); \
   template hipError_t diag_general_launch<T>(int, T *, uint32_t, const uint32_t *, const uint32_t *, const uint32_t *, \
-                                             const uint16_t *, const T *, const T *, hipStream_t);           \
+                                             const uint16_t *, const T *, const uint32_t *, const T *, const T *, \
+                                             hipStream_t);                                                   \
   template hipError_t set_values_launch<T>(T *, const uint32_t *, uint32_t, T, hipStream_t);                  \
   template hipError_t vec_map_launch<T>(int, T *, const T *, T, T, size_t, hipStream_t);                      \
   template hipError_t vec_reduce_launch<T>(int, T *, const T *, const T *, T, size_t, hipStream_t, double *);

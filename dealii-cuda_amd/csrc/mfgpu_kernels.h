@@ -65,8 +65,8 @@ hipError_t x_launch(int n, const ApplyArgs<T> &a, const double *S, const double 
                     hipStream_t st, bool configure_only, size_t *lds_out, int *occupancy);
 // general-Jacobian cell loop (mfgpu_kernels_g.hip; 3D, two-pass mode, conforming meshes) and its setup fold
 template <typename T>
-hipError_t g_launch(int n, const ApplyArgs<T> &a, const double *S, const double *Dt, uint32_t grid, hipStream_t st,
-                    bool configure_only, size_t *lds_out, int *occupancy);
+hipError_t g_launch(int n, const ApplyArgs<T> &a, const double *S, const double *Dt, bool hn, uint32_t grid,
+                    hipStream_t st, bool configure_only, size_t *lds_out, int *occupancy);
 template <typename T>
 hipError_t fold_general_launch(T *M, const T *coef, const T *jxw, const T *jinv, const uint32_t *order,
                                uint32_t n_cells, uint32_t nd, hipStream_t st);
@@ -92,7 +92,8 @@ hipError_t diag_launch(int dim, int n, T *diag, uint32_t n_batches, const uint32
 template <typename T>
 hipError_t diag_general_launch(int n, T *diag, uint32_t n_batches, const uint32_t *batch_cell_off,
                                const uint32_t *batch_dof_off, const uint32_t *bdofs, const uint16_t *lmap,
-                               const T *metric, const T *tab, hipStream_t st);
+                               const T *metric, const uint32_t *cmask, const T *hn_weights, const T *tab,
+                               hipStream_t st);
 template <typename T>
 hipError_t set_values_launch(T *v, const uint32_t *idx, uint32_t n, T value, hipStream_t st);
 // op: 0 sadd (v = s v + a w), 1 equ (v = a w), 2 scale (v *= w), 3 divide (v /= w), 4 invert, 5 mul (v *= a)

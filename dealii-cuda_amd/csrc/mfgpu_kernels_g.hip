@@ -6,7 +6,7 @@
 // mfgpu_create folds once (fold_general_kernel): 48 B per point are streamed instead of the reference's
 // 72 (J^-1) + 8 (JxW) + 8 (coefficient).
 //
-// 3D, two-pass scatter mode, no hanging nodes.  The batch machinery is apply_batches_x's (persistent
+// 3D, two-pass scatter mode; hanging nodes through the same constraint passes as apply_batches_x (template HN).  The batch machinery is apply_batches_x's (persistent
 // workgroups, XCD-aware batch ranges, aliased source/accumulator array, x-pencil index runs from global
 // memory, next batch's loads in flight).  The cell pipeline needs all three reference-gradient components
 // at the same point, so they go through LDS: 11 barrier-separated stages per chunk,
@@ -30,7 +30,7 @@ __device__ __forceinline__ int gix_at(const uint32_t (&w)[(n + 1) / 2], int i) {
   return (int)((w[i >> 1] >> (16 * (i & 1))) & 0xffffu);
 }
 
-template <int n, typename T>
+template <int n, typename T, bool HN>
 __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2)))
 apply_batches_g(const ApplyArgs<T> A, const Tables<T, n> tab) {
   constexpr int kBlock = 256;
@@ -47,6 +47,7 @@ apply_batches_g(const ApplyArgs<T> A, const Tables<T, n> tab) {
   T *Gxb = Wb + CHND;
   T *Gyb = Gxb + CHND;
   T *Gzb = Gyb + CHND;
+  T *Wl = Gzb + CHND;  // hanging-node weights (HN only)
 
   const int tid = threadIdx.x;
   uint32_t b, bstride, bend;
@@ -135,6 +136,8 @@ apply_batches_g(const ApplyArgs<T> A, const Tables<T, n> tab) {
   };
   auto chunk_count = [&](int ncell_, int base_) { return (ncell_ - base_ < CH ? ncell_ - base_ : CH) * nd; };
 
+  if (HN)
+    for (int t = tid; t < n2; t += kBlock) Wl[t] = A.hn_weights[t];
   uint32_t G[kGU];
   T SV[kGU];
   uint32_t IX[kMaxChunks][NW];
@@ -200,6 +203,35 @@ apply_batches_g(const ApplyArgs<T> A, const Tables<T, n> tab) {
       if (k == kMaxChunks - 1 && has_nb) load_src(Gn, SVn);
       if (k == 1 && has_nb) load_ix(c0n, ncelln, IXn);
       T u[n], v[n], w[n], g[n];
+      unsigned mask = 0;
+      bool any_mask = false;
+      if (HN) {
+        if (act) mask = A.cmask[(size_t)c0 + base + lc];
+        any_mask = __syncthreads_or(mask != 0) != 0;
+      }
+      if (HN && any_mask) {
+        // resolve_hanging_nodes_shmem<NOTRANSPOSE>: x, then y, then z (hanging_nodes.cuh:767-777); only the
+        // pencils on a constrained face or edge take the y / z round trips
+        bool type;
+        if (act) {
+          if (mask && hn_flag3<n, 0>(mask, pa, pb, type)) hn_pencil<n, T, false, true>(Wl, type, U[k]);
+          lds_store<n>(Wc + bx, 1, U[k]);
+        }
+        __syncthreads();
+        if (act && mask && hn_flag3<n, 1>(mask, pb, pa, type)) {
+          lds_load<n>(Wc + by, n, u);
+          hn_pencil<n, T, false, true>(Wl, type, u);
+          lds_store<n>(Wc + by, n, u);
+        }
+        __syncthreads();
+        if (act && mask && hn_flag3<n, 2>(mask, pa, pb, type)) {
+          lds_load<n>(Wc + bz, n2, u);
+          hn_pencil<n, T, false, true>(Wl, type, u);
+          lds_store<n>(Wc + bz, n2, u);
+        }
+        __syncthreads();
+        if (act) lds_load<n>(Wc + bx, 1, U[k]);
+      }
       // P0: interpolate along x
       if (act) {
         mvt<n, 1>(tab.S, U[k], v);
@@ -291,6 +323,30 @@ apply_batches_g(const ApplyArgs<T> A, const Tables<T, n> tab) {
       if (act) {
         lds_load<n>(Wc + bx, 1, u);
         mv<n, 1>(tab.S, u, v);
+      }
+      if (HN && any_mask) {
+        // resolve_hanging_nodes_shmem<TRANSPOSE>: the passes commute; y, z, then x (the index set's pencil)
+        bool type;
+        if (act) lds_store<n>(Wc + bx, 1, v);
+        __syncthreads();
+        if (act && mask && hn_flag3<n, 1>(mask, pb, pa, type)) {
+          lds_load<n>(Wc + by, n, v);
+          hn_pencil<n, T, true, true>(Wl, type, v);
+          lds_store<n>(Wc + by, n, v);
+        }
+        __syncthreads();
+        if (act && mask && hn_flag3<n, 2>(mask, pa, pb, type)) {
+          lds_load<n>(Wc + bz, n2, v);
+          hn_pencil<n, T, true, true>(Wl, type, v);
+          lds_store<n>(Wc + bz, n2, v);
+        }
+        __syncthreads();
+        if (act) {
+          lds_load<n>(Wc + bx, 1, v);
+          if (mask && hn_flag3<n, 0>(mask, pa, pb, type)) hn_pencil<n, T, true, true>(Wl, type, v);
+        }
+      }
+      if (act) {
 #pragma unroll
         for (int i = 0; i < n; ++i) lds_add(&ua[gix_at<n>(IX[k], i)], v[i]);
       }
@@ -361,19 +417,19 @@ template <int n, typename T>
 static size_t g_lds_bytes(uint32_t nb_max) {
   constexpr int nd = n * n * n;
   constexpr int CH = 256 / (n * n);
-  return (size_t)(nb_max + 4 * CH * nd) * sizeof(T);
+  return (size_t)(nb_max + 4 * CH * nd + n * n) * sizeof(T);
 }
 
-template <int n, typename T>
+template <int n, typename T, bool HN>
 static hipError_t g_run(const ApplyArgs<T> &a, const double *S, const double *Dt, uint32_t grid, hipStream_t st,
                         bool configure_only, size_t *lds_out, int *occupancy) {
   const size_t lds = g_lds_bytes<n, T>(a.nb_max);
   if (lds_out) *lds_out = lds;
   if (configure_only) {
-    hipError_t e = hipFuncSetAttribute((const void *)apply_batches_g<n, T>,
+    hipError_t e = hipFuncSetAttribute((const void *)apply_batches_g<n, T, HN>,
                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     if (e == hipSuccess && occupancy)
-      e = hipOccupancyMaxActiveBlocksPerMultiprocessor(occupancy, apply_batches_g<n, T>, 256, lds);
+      e = hipOccupancyMaxActiveBlocksPerMultiprocessor(occupancy, apply_batches_g<n, T, HN>, 256, lds);
     return e;
   }
   Tables<T, n> tab;
@@ -381,22 +437,22 @@ static hipError_t g_run(const ApplyArgs<T> &a, const double *S, const double *Dt
     tab.S[i] = (T)S[i];
     tab.Dt[i] = (T)Dt[i];
   }
-  hipLaunchKernelGGL((apply_batches_g<n, T>), dim3(grid), dim3(256), lds, st, a, tab);
+  hipLaunchKernelGGL((apply_batches_g<n, T, HN>), dim3(grid), dim3(256), lds, st, a, tab);
   return hipGetLastError();
 }
 
 template <typename T>
-hipError_t g_launch(int n, const ApplyArgs<T> &a, const double *S, const double *Dt, uint32_t grid, hipStream_t st,
-                    bool configure_only, size_t *lds_out, int *occupancy) {
+hipError_t g_launch(int n, const ApplyArgs<T> &a, const double *S, const double *Dt, bool hn, uint32_t grid,
+                    hipStream_t st, bool configure_only, size_t *lds_out, int *occupancy) {
+#define G_CASE(N)                                                                                 \
+  case N:                                                                                         \
+    return hn ? g_run<N, T, true>(a, S, Dt, grid, st, configure_only, lds_out, occupancy)         \
+              : g_run<N, T, false>(a, S, Dt, grid, st, configure_only, lds_out, occupancy);
   switch (n) {
-    case 2: return g_run<2, T>(a, S, Dt, grid, st, configure_only, lds_out, occupancy);
-    case 3: return g_run<3, T>(a, S, Dt, grid, st, configure_only, lds_out, occupancy);
-    case 4: return g_run<4, T>(a, S, Dt, grid, st, configure_only, lds_out, occupancy);
-    case 5: return g_run<5, T>(a, S, Dt, grid, st, configure_only, lds_out, occupancy);
-    case 6: return g_run<6, T>(a, S, Dt, grid, st, configure_only, lds_out, occupancy);
-    case 7: return g_run<7, T>(a, S, Dt, grid, st, configure_only, lds_out, occupancy);
+    G_CASE(2) G_CASE(3) G_CASE(4) G_CASE(5) G_CASE(6) G_CASE(7)
     default: return hipErrorInvalidValue;
   }
+#undef G_CASE
 }
 
 template <typename T>
@@ -409,8 +465,8 @@ hipError_t fold_general_launch(T *M, const T *coef, const T *jxw, const T *jinv,
 }
 
 #define INST(T)                                                                                              \
-  template hipError_t g_launch<T>(int, const ApplyArgs<T> &, const double *, const double *, uint32_t, hipStream_t, \
-                                  bool, size_t *, int *);                                                    \
+  template hipError_t g_launch<T>(int, const ApplyArgs<T> &, const double *, const double *, bool, uint32_t,        \
+                                  hipStream_t, bool, size_t *, int *);                                                    \
   template hipError_t fold_general_launch<T>(T *, const T *, const T *, const T *, const uint32_t *, uint32_t, \
                                              uint32_t, hipStream_t);
 INST(double)

@@ -6,7 +6,7 @@ import pytest
 
 import pymfgpu as mf
 from oracle import mf_oracle as o
-from util import deformed_oracle_desc, desc_from_oracle
+from util import deform, deformed_oracle_desc, desc_from_oracle, oracle_desc_from_mesh
 from test_gpu import gpu_vmult, rel
 
 pytestmark = pytest.mark.gpu
@@ -105,3 +105,24 @@ def test_general_jacobian_inverse_diagonal_and_pcg(p, n):
         rz = rz_new
     assert its < 2999
     assert np.linalg.norm(x.to_host() - x_ref) <= 1e-8 * np.linalg.norm(x_ref)
+
+
+@pytest.mark.parametrize("p,nref", [(1, 4), (2, 4), (4, 4), (3, 5)])
+def test_general_jacobian_with_hanging_nodes(p, nref):
+    """N3 on an adaptive mesh: the bmop ADAPTIVE_GRID mesh (hanging-node masks, substituted dof indices) with a
+    full inverse Jacobian per quadrature point; vmult, vmult_add and the inverse diagonal against the oracle."""
+    mesh = mf.Mesh.adaptive(3, p, nref)
+    od = deform(oracle_desc_from_mesh(mesh, dtype=np.float64), seed=nref)
+    assert od.constraint_mask is not None and not od.uniform_j0
+    desc, keep = desc_from_oracle(od)
+    assert desc.flags & mf.HANGING_NODES and not (desc.flags & mf.UNIFORM_J0)
+    op = mf.Operator(desc, keep)
+    assert op.kernel_name() == "apply_batches_g"
+    rng = np.random.default_rng(11)
+    x, y0 = rng.standard_normal(od.n_dofs), rng.standard_normal(od.n_dofs)
+    assert rel(gpu_vmult(op, x), o.vmult(od, x)) <= 1e-12
+    assert rel(gpu_vmult(op, x, y0=y0), o.vmult_add(od, y0, x)) <= 1e-12
+    dinv = mf.DeviceVector(od.n_dofs)
+    op.compute_inverse_diagonal(dinv)
+    mf.synchronize()
+    np.testing.assert_allclose(dinv.to_host(), o.compute_inverse_diagonal(od), rtol=1e-12)

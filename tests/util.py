@@ -77,6 +77,20 @@ def emulate_plan_vmult(od: o.Desc, plan: "mf.Plan", src, dst_in=None, twopass=Fa
     return dst
 
 
+def deform(od: o.Desc, eps=0.12, seed=0):
+    """General-geometry version of a Cartesian oracle Desc (any mesh, hanging-node masks kept): per quadrature
+    point F = h_cell (I + eps R), R random in [-1,1]; inv_jac = F^-1, JxW scaled by det(F) / h^dim."""
+    assert od.uniform_j0
+    nc, nd, dim = od.n_cells, od.nd, od.dim
+    h = (1.0 / od.inv_jac.astype(np.float64)).reshape(nc, 1, 1, 1)
+    F = h * (np.eye(dim) + eps * np.random.default_rng(seed).uniform(-1.0, 1.0, (nc, nd, dim, dim)))
+    det = np.linalg.det(F)
+    assert det.min() > 0
+    jxw = od.JxW.astype(np.float64).reshape(nc, nd) / h.reshape(nc, 1) ** dim * det
+    return o.Desc(dim, od.degree, od.n_dofs, od.loc2glob, jxw, np.linalg.inv(F), od.coefficient, od.constrained,
+                  od.constraint_mask, od.dtype, od.shape_values, od.shape_gradients, od.weights)
+
+
 def deformed_oracle_desc(p, n, eps=0.12, seed=0, dtype=np.float64):
     """3D oracle Desc with GENERAL geometry data: the uniform cube's connectivity with a
     synthetic reference->physical Jacobian F = h (I + eps R) per quadrature point (R random in [-1,1]), i.e.
