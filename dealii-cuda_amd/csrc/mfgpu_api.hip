@@ -477,7 +477,8 @@ int mfgpu_create(const mfgpu_desc *desc, mfgpu_handle **out) {
     h->gk = true;
     h->xk = h->wave = h->plane = h->ls = false;
   }
-  int rc = build_plan(dplan, h->plan);
+  // apply_batches_x unrolls 4 chunks at p=3 (64-cell batches = 13^3 dofs like p=4); everything else 3
+  int rc = build_plan(dplan, h->plan, (h->xk && d.degree == 3) ? 4u : 3u);
   if (rc) {
     delete h;
     return rc;

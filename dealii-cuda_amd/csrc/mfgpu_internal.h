@@ -50,7 +50,8 @@ struct Plan {
 };
 
 // Build the plan from a description (validates it).  Returns 0 or MFGPU_E*.
-int build_plan(const mfgpu_desc &d, Plan &plan);
+// max_chunks: chunks of cells per batch the cell-loop kernel unrolls (3; apply_batches_x at p=3: 4)
+int build_plan(const mfgpu_desc &d, Plan &plan, uint32_t max_chunks = 3);
 
 // Derive the kernel's 1D tables from the reference-layout tables T[dof*n+q]:
 //   S[i*n+q]  = shape_values (interpolation nodal -> quadrature points)

@@ -171,11 +171,16 @@ __device__ __forceinline__ void cell_pipeline_x(const bool act, const int pa, co
 
 template <int n>
 constexpr int x_waves_per_simd() { return n <= 5 ? 3 : 2; }
+// chunks of cells per batch (unrolled; the planner gets the same number from mfgpu_api.hip): p=3 needs a fourth
+// chunk of 16 cells to reach the 64-cell batch (13^3 dofs) that p=4 reaches with 27 cells in three chunks
+template <int n>
+constexpr int x_chunks() { return n == 4 ? 4 : kMaxChunks; }
 
 template <int n, typename T, bool HN>
 __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(x_waves_per_simd<n>())))
 apply_batches_x(const ApplyArgs<T> A, const Tables<T, n> tab) {
   constexpr int kBlock = 256;
+  constexpr int KC = x_chunks<n>();
   constexpr int kGU = (max_batch_dofs(kBlock) + kBlock - 1) / kBlock;
   constexpr int n2 = n * n, nd = n2 * n;
   constexpr int P = n2;
@@ -273,10 +278,10 @@ apply_batches_x(const ApplyArgs<T> A, const Tables<T, n> tab) {
     for (int j = 0; j < kGU; ++j) sv_[j] = A.src[g_[j] & 0x7fffffffu];
   };
   // x-pencil index runs of the thread's cell in every chunk of a batch
-  auto load_ix = [&](uint32_t c0_, int ncell_, uint32_t (&ix_)[kMaxChunks][NW]) {
+  auto load_ix = [&](uint32_t c0_, int ncell_, uint32_t (&ix_)[KC][NW]) {
     const uint32_t *lx = reinterpret_cast<const uint32_t *>(A.lmapx);
 #pragma unroll
-    for (int k = 0; k < kMaxChunks; ++k) {
+    for (int k = 0; k < KC; ++k) {
       int cell = k * CH + lc;
       cell = cell < ncell_ ? cell : ncell_ - 1;
       const uint32_t *p = lx + ((size_t)(c0_ + cell) * P + (lane_on ? pen : 0)) * NW;
@@ -308,7 +313,7 @@ apply_batches_x(const ApplyArgs<T> A, const Tables<T, n> tab) {
 
   uint32_t G[kGU];
   T SV[kGU];
-  uint32_t IX[kMaxChunks][NW];
+  uint32_t IX[KC][NW];
   load_meta(b, c0, ncell, d0, nb, nint, hoff);
   load_dofs(d0, nb, G);
   load_ix(c0, ncell, IX);
@@ -344,16 +349,16 @@ apply_batches_x(const ApplyArgs<T> A, const Tables<T, n> tab) {
     int nbn = nb, ncelln = ncell, nintn = nint;
     uint32_t Gn[kGU];
     T SVn[kGU];
-    uint32_t IXn[kMaxChunks][NW];
+    uint32_t IXn[KC][NW];
     if (has_nb) {
       load_meta(bn, c0n, ncelln, d0n, nbn, nintn, hoffn);
       load_dofs(d0n, nbn, Gn);
     }
     __syncthreads();
     // ---- 2. source pencils of every chunk -> registers; afterwards the array is the accumulator
-    T U[kMaxChunks][n];
+    T U[KC][n];
 #pragma unroll
-    for (int k = 0; k < kMaxChunks; ++k) {
+    for (int k = 0; k < KC; ++k) {
       if (k * CH < ncell) {  // uniform
 #pragma unroll
         for (int i = 0; i < n; ++i) U[k][i] = ua[ix_at<n>(IX[k], i)];
@@ -369,10 +374,10 @@ apply_batches_x(const ApplyArgs<T> A, const Tables<T, n> tab) {
     }
     // (the first add into the accumulator is at least six barriers away)
 
-    // ---- 3. cells.  The chunk loop is fully unrolled (at most kMaxChunks chunks, enforced by the planner):
+    // ---- 3. cells.  The chunk loop is fully unrolled (at most KC chunks, enforced by the planner):
     // in straight-line code hipcc emits counted vmcnt waits and younger loads stay in flight.
 #pragma unroll
-    for (int k = 0; k < kMaxChunks; ++k) {
+    for (int k = 0; k < KC; ++k) {
       const int base = k * CH;
       if (base >= ncell) continue;  // uniform
       const bool act = lane_on && (base + lc < ncell);
@@ -388,7 +393,7 @@ apply_batches_x(const ApplyArgs<T> A, const Tables<T, n> tab) {
       // next batch's gather and index runs: issued in the LAST chunk, where the source pencils of the
       // other chunks are dead (register budget of three waves per SIMD), after this chunk's stream prefetch
       // so that the counted wait for the stream leaves them in flight
-      if (k == kMaxChunks - 1 && has_nb) load_src(Gn, SVn);  // compile-time position: U[k'] are dead
+      if (k == KC - 1 && has_nb) load_src(Gn, SVn);  // compile-time position: U[k'] are dead
       if (k == 1 && has_nb) load_ix(c0n, ncelln, IXn);
       unsigned mask = 0;
       bool any_mask = false;
@@ -400,7 +405,7 @@ apply_batches_x(const ApplyArgs<T> A, const Tables<T, n> tab) {
         if (cnt_next > 0) stage(cnt_next);
       });
     }
-    if (has_nb && ncell <= (kMaxChunks - 1) * CH) {  // short batch (ragged meshes): no overlap
+    if (has_nb && ncell <= (KC - 1) * CH) {  // short batch (ragged meshes): no overlap
       load_src(Gn, SVn);
       if (ncell <= CH) load_ix(c0n, ncelln, IXn);
     }
@@ -443,7 +448,7 @@ apply_batches_x(const ApplyArgs<T> A, const Tables<T, n> tab) {
       SV[j] = SVn[j];
     }
 #pragma unroll
-    for (int k = 0; k < kMaxChunks; ++k)
+    for (int k = 0; k < KC; ++k)
 #pragma unroll
       for (int q = 0; q < NW; ++q) IX[k][q] = IXn[k][q];
   }

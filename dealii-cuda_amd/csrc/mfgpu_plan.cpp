@@ -58,7 +58,7 @@ int derive_tables(int n, const double *sv, const double *sg, std::vector<double>
   return 0;
 }
 
-static void default_batch_limits(const mfgpu_desc &d, uint32_t &max_cells, uint32_t &max_dofs) {
+static void default_batch_limits(const mfgpu_desc &d, uint32_t max_chunks, uint32_t &max_cells, uint32_t &max_dofs) {
   const int p = d.degree, dim = d.dim;
   max_dofs = d.max_dofs_per_batch ? d.max_dofs_per_batch : 2304u;
   // the kernel keeps a batch's dof list and source values in registers: kGU * kBlock = 9 * 256 dofs
@@ -75,14 +75,14 @@ static void default_batch_limits(const mfgpu_desc &d, uint32_t &max_cells, uint3
     const uint32_t cap = std::max<uint32_t>(1u, d.n_cells / 4096u);
     max_cells = std::min(max_cells, cap);
   }
-  // the kernel unrolls at most 3 chunks of CH = threads / n^(dim-1) cells per batch (mfgpu_kernels.hip)
+  // the kernel unrolls at most max_chunks chunks of CH = threads / n^(dim-1) cells per batch
   const uint32_t threads = d.max_dofs_per_batch && d.max_dofs_per_batch <= 768 ? 64u : 256u;
   const uint32_t ch = std::max<uint32_t>(1u, threads / (uint32_t)ipow(p + 1, dim - 1));
-  max_cells = std::min(max_cells, 3u * ch);
+  max_cells = std::min(max_cells, max_chunks * ch);
   if (max_cells < 1) max_cells = 1;
 }
 
-int build_plan(const mfgpu_desc &d, Plan &P) {
+int build_plan(const mfgpu_desc &d, Plan &P, uint32_t max_chunks) {
   if (d.dim != 2 && d.dim != 3) {
     set_error("dim must be 2 or 3");
     return MFGPU_EINVAL;
@@ -127,7 +127,7 @@ int build_plan(const mfgpu_desc &d, Plan &P) {
     return MFGPU_EUNSUPPORTED;
   }
   uint32_t Bmax, NBmax;
-  default_batch_limits(d, Bmax, NBmax);
+  default_batch_limits(d, max_chunks, Bmax, NBmax);
 
   // dof -> cells incidence (CSR)
   std::vector<uint32_t> dc_off(N + 1, 0);
