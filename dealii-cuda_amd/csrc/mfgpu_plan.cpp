@@ -70,7 +70,7 @@ static void default_batch_limits(const mfgpu_desc &d, uint32_t max_chunks, uint3
   } else {
     int m = 1;
     while ((uint64_t)ipow((m + 1) * p + 1, dim) <= max_dofs) ++m;
-    max_cells = (uint32_t)std::min(ipow(m, dim), 64);
+    max_cells = (uint32_t)ipow(m, dim);  // the chunk limit below is the binding one at low degree
     // keep enough workgroups per launch on small meshes
     const uint32_t cap = std::max<uint32_t>(1u, d.n_cells / 4096u);
     max_cells = std::min(max_cells, cap);
