@@ -68,9 +68,17 @@ static void default_batch_limits(const mfgpu_desc &d, uint32_t max_chunks, uint3
   if (d.max_cells_per_batch) {
     max_cells = d.max_cells_per_batch;
   } else {
+    // the largest near-cubic box of cells (edge lengths m or m + 1) whose dofs fit: 3x3x3 at p=4, 4x4x4 at
+    // p=3, 3x2x2 at p=5 (the cube 2x2x2 would leave the dof budget half empty); at low degree the chunk
+    // limit below is the binding one
     int m = 1;
     while ((uint64_t)ipow((m + 1) * p + 1, dim) <= max_dofs) ++m;
-    max_cells = (uint32_t)ipow(m, dim);  // the chunk limit below is the binding one at low degree
+    uint64_t best = (uint64_t)ipow(m, dim);
+    for (int k = 1; k < dim; ++k) {  // k edges of length m + 1, dim - k of length m
+      const uint64_t dofs = (uint64_t)ipow((m + 1) * p + 1, k) * (uint64_t)ipow(m * p + 1, dim - k);
+      if (dofs <= max_dofs) best = (uint64_t)ipow(m + 1, k) * (uint64_t)ipow(m, dim - k);
+    }
+    max_cells = (uint32_t)best;
     // keep enough workgroups per launch on small meshes
     const uint32_t cap = std::max<uint32_t>(1u, d.n_cells / 4096u);
     max_cells = std::min(max_cells, cap);
