@@ -42,8 +42,10 @@ apply_batches_g(const ApplyArgs<T> A, const Tables<T, n> tab) {
   constexpr int NW = (n + 1) / 2;
   constexpr int PF = (CHND + kBlock - 1) / kBlock;  // quadrature points per thread in the pointwise stage
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
-  T *ua = reinterpret_cast<T *>(smem_raw);  // gathered source values, then the accumulator
-  T *Wb = ua + A.nb_max;                    // w, later the result r (aliased: w is dead after the D_y stage)
+  // gathered source values, then the accumulator: always double (ds_add_f32 is far slower than ds_add_f64 on
+  // gfx950, see apply_batches_x)
+  double *ua = reinterpret_cast<double *>(smem_raw);
+  T *Wb = reinterpret_cast<T *>(ua + A.nb_max);  // w, later the result r (aliased: w is dead after the D_y stage)
   T *Gxb = Wb + CHND;
   T *Gyb = Gxb + CHND;
   T *Gzb = Gyb + CHND;
@@ -150,12 +152,12 @@ apply_batches_g(const ApplyArgs<T> A, const Tables<T, n> tab) {
     // writes dst = src (constraint_handler_gpu.cu:258-259,286)
     {
       const int l = lane();
-      T *ul = ua + l;
+      double *ul = ua + l;
 #pragma unroll
       for (int j = 0; j < kGU; ++j) {
         const bool con = (G[j] >> 31) != 0;
         if (l < nb - j * kBlock) {
-          ul[j * kBlock] = con ? T(0) : SV[j];
+          ul[j * kBlock] = con ? 0.0 : (double)SV[j];
           if (con && l < nint - j * kBlock) {
             T *d = A.dst + (G[j] & 0x7fffffffu);
             *d = A.add ? *d + SV[j] : SV[j];
@@ -181,15 +183,15 @@ apply_batches_g(const ApplyArgs<T> A, const Tables<T, n> tab) {
     for (int k = 0; k < kMaxChunks; ++k)
       if (k * CH < ncell) {
 #pragma unroll
-        for (int i = 0; i < n; ++i) U[k][i] = ua[gix_at<n>(IX[k], i)];
+        for (int i = 0; i < n; ++i) U[k][i] = (T)ua[gix_at<n>(IX[k], i)];
       }
     __syncthreads();
     {
       const int l = lane();
-      T *ul = ua + l;
+      double *ul = ua + l;
 #pragma unroll
       for (int j = 0; j < kGU; ++j)
-        if (l < nb - j * kBlock) ul[j * kBlock] = T(0);
+        if (l < nb - j * kBlock) ul[j * kBlock] = 0.0;
     }
 
     // ---- 3. cells
@@ -348,7 +350,7 @@ apply_batches_g(const ApplyArgs<T> A, const Tables<T, n> tab) {
       }
       if (act) {
 #pragma unroll
-        for (int i = 0; i < n; ++i) lds_add(&ua[gix_at<n>(IX[k], i)], v[i]);
+        for (int i = 0; i < n; ++i) lds_add(&ua[gix_at<n>(IX[k], i)], (double)v[i]);
       }
     }
     if (has_nb && ncell <= (kMaxChunks - 1) * CH) {  // short batch (ragged meshes): no overlap
@@ -360,7 +362,7 @@ apply_batches_g(const ApplyArgs<T> A, const Tables<T, n> tab) {
     // ---- 4. scatter: interior dofs -> dst, partial sums of shared dofs -> halo (reduce pass sums them)
     {
       const int l = lane();
-      const T *ul = ua + l;
+      const double *ul = ua + l;
       T *hl = A.halo + hoff + l - nint;
       T old[kGU];
       if (A.add) {
@@ -370,9 +372,9 @@ apply_batches_g(const ApplyArgs<T> A, const Tables<T, n> tab) {
 #pragma unroll
       for (int j = 0; j < kGU; ++j) {
         if (l < nint - j * kBlock) {
-          if (!(G[j] >> 31)) A.dst[G[j]] = A.add ? old[j] + ul[j * kBlock] : ul[j * kBlock];
+          if (!(G[j] >> 31)) A.dst[G[j]] = A.add ? old[j] + (T)ul[j * kBlock] : (T)ul[j * kBlock];
         } else if (l < nb - j * kBlock) {
-          hl[j * kBlock] = ul[j * kBlock];
+          hl[j * kBlock] = (T)ul[j * kBlock];
         }
       }
     }
@@ -417,7 +419,7 @@ template <int n, typename T>
 static size_t g_lds_bytes(uint32_t nb_max) {
   constexpr int nd = n * n * n;
   constexpr int CH = 256 / (n * n);
-  return (size_t)(nb_max + 4 * CH * nd + n * n) * sizeof(T);
+  return (size_t)nb_max * sizeof(double) + (size_t)(4 * CH * nd + n * n) * sizeof(T);
 }
 
 template <int n, typename T, bool HN>

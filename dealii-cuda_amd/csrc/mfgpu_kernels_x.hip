@@ -42,7 +42,7 @@ __device__ __forceinline__ int ix_at(const uint32_t (&w)[(n + 1) / 2], int i) {
 template <int n, typename T, bool HN, typename StageNext>
 __device__ __forceinline__ void cell_pipeline_x(const bool act, const int pa, const int pb, const unsigned mask,
                                                 const bool any_mask, T (&u)[n], const uint32_t (&ixw)[(n + 1) / 2],
-                                                T *acc, T *Wc, T *Rc, const T *cf, const T *Wl,
+                                                double *acc, T *Wc, T *Rc, const T *cf, const T *Wl,
                                                 const Tables<T, n> &tab, StageNext &&stage_next) {
   constexpr int n2 = n * n;
   const int bx = n * pa + n2 * pb;  // x-pencil (y = pa, z = pb), stride 1
@@ -165,7 +165,7 @@ __device__ __forceinline__ void cell_pipeline_x(const bool act, const int pa, co
   }
   if (act) {
 #pragma unroll
-    for (int i = 0; i < n; ++i) lds_add(&acc[ix_at<n>(ixw, i)], v[i]);
+    for (int i = 0; i < n; ++i) lds_add(&acc[ix_at<n>(ixw, i)], (double)v[i]);
   }
 }
 
@@ -191,8 +191,11 @@ apply_batches_x(const ApplyArgs<T> A, const Tables<T, n> tab) {
   constexpr int kPark = 4;
   static_assert(CH >= 1, "a cell's pencils must fit into the workgroup");
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
-  T *ua = reinterpret_cast<T *>(smem_raw);  // gathered source values, then the accumulator
-  T *Wb = ua + A.nb_max;
+  // gathered source values, then the accumulator: always double.  ds_add_f32 is serviced far more slowly
+  // than ds_add_f64 on gfx950 (float build: 82 M vs 44 M LDS-active cycles per launch at identical
+  // instruction counts, profiles/r01_notes.md), and the float result gains accuracy
+  double *ua = reinterpret_cast<double *>(smem_raw);
+  T *Wb = reinterpret_cast<T *>(ua + A.nb_max);
   T *Rb = Wb + CHND;
   T *Cb = Rb + CHND;
   T *Wl = Cb + CHND;
@@ -327,12 +330,12 @@ apply_batches_x(const ApplyArgs<T> A, const Tables<T, n> tab) {
     // previous batch's scatter, so no barrier separates the two.
     {
       const int l = lane();
-      T *ul = ua + l;
+      double *ul = ua + l;
 #pragma unroll
       for (int j = 0; j < kGU; ++j) {
         const bool con = (G[j] >> 31) != 0;
         if (l < nb - j * kBlock) {
-          ul[j * kBlock] = con ? T(0) : SV[j];
+          ul[j * kBlock] = con ? 0.0 : (double)SV[j];
           if (con && l < nint - j * kBlock) {
             T *d = A.dst + (G[j] & 0x7fffffffu);
             *d = A.add ? *d + SV[j] : SV[j];
@@ -361,16 +364,16 @@ apply_batches_x(const ApplyArgs<T> A, const Tables<T, n> tab) {
     for (int k = 0; k < KC; ++k) {
       if (k * CH < ncell) {  // uniform
 #pragma unroll
-        for (int i = 0; i < n; ++i) U[k][i] = ua[ix_at<n>(IX[k], i)];
+        for (int i = 0; i < n; ++i) U[k][i] = (T)ua[ix_at<n>(IX[k], i)];
       }
     }
     __syncthreads();
     {
       const int l = lane();
-      T *ul = ua + l;
+      double *ul = ua + l;
 #pragma unroll
       for (int j = 0; j < kGU; ++j)
-        if (l < nb - j * kBlock) ul[j * kBlock] = T(0);
+        if (l < nb - j * kBlock) ul[j * kBlock] = 0.0;
     }
     // (the first add into the accumulator is at least six barriers away)
 
@@ -416,7 +419,7 @@ apply_batches_x(const ApplyArgs<T> A, const Tables<T, n> tab) {
     // contiguous halo slots (reduce_shared)
     {
       const int l = lane();
-      const T *ul = ua + l;
+      const double *ul = ua + l;
       T *hl = A.halo + hoff + l - nint;
 #pragma unroll
       for (int j = 0; j < kPark; ++j) G[kGU - kPark + j] = Gp[j * kBlock + tid];
@@ -428,9 +431,9 @@ apply_batches_x(const ApplyArgs<T> A, const Tables<T, n> tab) {
 #pragma unroll
       for (int j = 0; j < kGU; ++j) {
         if (l < nint - j * kBlock) {
-          if (!(G[j] >> 31)) A.dst[G[j]] = A.add ? old[j] + ul[j * kBlock] : ul[j * kBlock];
+          if (!(G[j] >> 31)) A.dst[G[j]] = A.add ? old[j] + (T)ul[j * kBlock] : (T)ul[j * kBlock];
         } else if (l < nb - j * kBlock) {
-          hl[j * kBlock] = ul[j * kBlock];  // constrained shared dofs: value ignored by reduce_shared
+          hl[j * kBlock] = (T)ul[j * kBlock];  // constrained shared dofs: value ignored by reduce_shared
         }
       }
     }
@@ -458,7 +461,7 @@ template <int n, typename T>
 static size_t x_lds_bytes(uint32_t nb_max) {
   constexpr int nd = n * n * n;
   constexpr int CH = 256 / (n * n);
-  return (size_t)(nb_max + 3 * CH * nd + n * n) * sizeof(T) + 4 * 256 * sizeof(uint32_t);
+  return (size_t)nb_max * sizeof(double) + (size_t)(3 * CH * nd + n * n) * sizeof(T) + 4 * 256 * sizeof(uint32_t);
 }
 
 template <int n, typename T, bool HN>

@@ -11,10 +11,11 @@ n = int(sys.argv[1]) if len(sys.argv) > 1 else 54
 steps = int(sys.argv[2]) if len(sys.argv) > 2 else 20
 bc = int(sys.argv[3]) if len(sys.argv) > 3 else 0
 p = int(sys.argv[4]) if len(sys.argv) > 4 else 4
-mesh = mf.Mesh.uniform(3, p, n)
+nt = mf.F32 if len(sys.argv) > 5 and sys.argv[5] == "f32" else mf.F64
+mesh = mf.Mesh.uniform(3, p, n, number_type=nt)
 mesh.desc.max_cells_per_batch = bc
 op = mf.Operator(mesh.desc, mesh)
-dst, src = mf.DeviceVector(mesh.n_dofs), mf.DeviceVector(mesh.n_dofs)
+dst, src = mf.DeviceVector(mesh.n_dofs, nt), mf.DeviceVector(mesh.n_dofs, nt)
 dst.fill(0.1)
 for i in range(steps):
     dst.swap(src)
