@@ -31,6 +31,7 @@ struct mfgpu_handle {
   uint8_t *d_bflags = nullptr;
   uint16_t *d_lmap = nullptr;
   uint16_t *d_lmapx = nullptr;
+  uint16_t *d_perm = nullptr;  // apply_batches_x: bank-conflict-free lane -> pencil maps of the y- and z-stage
   void *d_coef = nullptr;
   uint32_t *d_cmask = nullptr, *d_orphans = nullptr;
   void *d_hnw = nullptr;
@@ -114,6 +115,34 @@ int create_typed(mfgpu_handle *h, const mfgpu_desc &d) {
   if ((rc = dev_upload(&h->d_bdofs, P.bdofs.data(), P.bdofs.size() * 4, acct))) return rc;
   if ((rc = dev_upload(&h->d_bflags, P.bflags.data(), P.bflags.size(), acct))) return rc;
   if ((rc = dev_upload(&h->d_lmap, P.lmap.data(), P.lmap.size() * 2, acct))) return rc;
+  if (h->xk && !h->hn && !getenv("MFGPU_NOPERM")) {
+    // Lane -> pencil maps of the y- and z-stage (see apply_batches_x).  LDS rules (MI355X_MICROARCH.md): a
+    // ds_read_b64 is served in 32-lane groups, a double occupies slot (index mod 32); ds_write_b64 / ds_read2_b64
+    // in 16-lane groups, slot (index mod 16).  All n elements of a pencil shift its base by the same stride, so
+    // only the bases matter: the pencil whose base has residue r mod 32 gets lane 32 k + r (k-th pencil with that
+    // residue) -- distinct slots in every 32-lane group, and in each of its 16-lane halves.  Residue classes with
+    // more than 8 pencils (4 pencils at p=4 in the y-stage, 2 in the z-stage) overflow into the idle lanes, which
+    // all sit in the last group.
+    const int n = P.n, n2 = n * n, PP = n2, CH = 256 / PP, ndl = n2 * n;
+    std::vector<uint16_t> perm(512, 0xffff);
+    for (int layout = 0; layout < 2; ++layout) {
+      uint16_t *lanes = perm.data() + 256 * layout;
+      std::vector<int> fill(32, 0), overflow;
+      for (int q = 0; q < CH * PP; ++q) {
+        const int cell = q / PP, pen = q % PP, a = pen % n, b = pen / n;
+        const int base = cell * ndl + (layout == 0 ? a + n2 * b : a + n * b);
+        const int r = base & 31;
+        if (fill[r] < 8) lanes[32 * fill[r]++ + r] = (uint16_t)q;
+        else overflow.push_back(q);
+      }
+      for (int l = 255; l >= 0 && !overflow.empty(); --l)
+        if (lanes[l] == 0xffff) {
+          lanes[l] = (uint16_t)overflow.back();
+          overflow.pop_back();
+        }
+    }
+    if ((rc = dev_upload(&h->d_perm, perm.data(), perm.size() * 2, acct))) return rc;
+  }
   if (h->xk || h->gk) {
     // x-pencil index runs (n contiguous entries of lmap) padded to whole 32-bit words
     const size_t n = (size_t)P.n, np = (n + 1) & ~(size_t)1, runs = P.lmap.size() / n;
@@ -291,6 +320,7 @@ int vmult_typed(mfgpu_handle *h, void *dst, const void *src, hipStream_t st, int
   a.bflags = h->d_bflags;
   a.lmap = h->d_lmap;
   a.lmapx = h->d_lmapx;
+  a.perm = h->d_perm;
   a.coef = (const T *)h->d_coef;
   a.cmask = h->d_cmask;
   a.hn_weights = (const T *)h->d_hnw;
@@ -520,6 +550,7 @@ void mfgpu_destroy(mfgpu_handle *h) {
   hipFree(h->d_bflags);
   hipFree(h->d_lmap);
   hipFree(h->d_lmapx);
+  hipFree(h->d_perm);
   hipFree(h->d_constrained);
   hipFree(h->d_tab2);
   hipFree(h->d_coef);

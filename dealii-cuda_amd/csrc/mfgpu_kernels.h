@@ -16,6 +16,7 @@ struct ApplyArgs {
   const uint8_t *bflags;
   const uint16_t *lmap;
   const uint16_t *lmapx;  // apply_batches_x: x-pencil index runs padded to 32-bit words, or nullptr
+  const uint16_t *perm;   // apply_batches_x: [2][256] lane -> pencil id of the y- and the z-stage, or nullptr (natural)
   const T *coef;          // folded a*J0^2*JxW (apply_batches_g: the 6 entries of a*JxW*J*J^T), plan cell order
   const uint32_t *cmask;  // plan cell order, or nullptr
   const T *hn_weights;    // [n*n] W[i*n+j] (device), or nullptr

@@ -40,14 +40,14 @@ __device__ __forceinline__ int ix_at(const uint32_t (&w)[(n + 1) / 2], int i) {
 // thread's x-pencil; ixw: batch-local dof ids of that pencil (packed 16-bit).  stage_next() is called
 // where the coefficient buffer is dead.
 template <int n, typename T, bool HN, typename StageNext>
-__device__ __forceinline__ void cell_pipeline_x(const bool act, const int pa, const int pb, const unsigned mask,
-                                                const bool any_mask, T (&u)[n], const uint32_t (&ixw)[(n + 1) / 2],
-                                                double *acc, T *Wc, T *Rc, const T *cf, const T *Wl,
+__device__ __forceinline__ void cell_pipeline_x(const bool act, const bool acty, const bool actz, const int pa, const int pb,
+                                                const unsigned mask, const bool any_mask, T (&u)[n],
+                                                const uint32_t (&ixw)[(n + 1) / 2], double *acc, T *Wc, T *Rc, const T *cf,
+                                                T *Wy, T *Ry, const T *Cy, T *Wz, T *Rz, const T *Cz, const T *Wl,
                                                 const Tables<T, n> &tab, StageNext &&stage_next) {
+
   constexpr int n2 = n * n;
   const int bx = n * pa + n2 * pb;  // x-pencil (y = pa, z = pb), stride 1
-  const int by = pa + n2 * pb;      // y-pencil (x = pa, z = pb), stride n
-  const int bz = pa + n * pb;       // z-pencil (x = pa, y = pb), stride n2
   T v[n], w[n], g[n], r[n];
   if (HN && any_mask) {
     // resolve_hanging_nodes_shmem<NOTRANSPOSE>: x, then y, then z (hanging_nodes.cuh:767-777)
@@ -58,16 +58,16 @@ __device__ __forceinline__ void cell_pipeline_x(const bool act, const int pa, co
     }
     __syncthreads();
     // only the pencils on a constrained face or edge change: everybody else skips the round trip
-    if (act && mask && hn_flag3<n, 1>(mask, pb, pa, type)) {
-      lds_load<n>(Wc + by, n, u);
+    if (acty && mask && hn_flag3<n, 1>(mask, pb, pa, type)) {
+      lds_load<n>(Wy, n, u);
       hn_pencil<n, T, false, true>(Wl, type, u);
-      lds_store<n>(Wc + by, n, u);
+      lds_store<n>(Wy, n, u);
     }
     __syncthreads();
-    if (act && mask && hn_flag3<n, 2>(mask, pa, pb, type)) {
-      lds_load<n>(Wc + bz, n2, u);
+    if (actz && mask && hn_flag3<n, 2>(mask, pa, pb, type)) {
+      lds_load<n>(Wz, n2, u);
       hn_pencil<n, T, false, true>(Wl, type, u);
-      lds_store<n>(Wc + bz, n2, u);
+      lds_store<n>(Wz, n2, u);
     }
     __syncthreads();
     if (act) lds_load<n>(Wc + bx, 1, u);
@@ -79,23 +79,23 @@ __device__ __forceinline__ void cell_pipeline_x(const bool act, const int pa, co
   }
   __syncthreads();
   // P1: interpolate along y
-  if (act) {
-    lds_load<n>(Wc + by, n, u);
+  if (acty) {
+    lds_load<n>(Wy, n, u);
     mvt<n, 1>(tab.S, u, v);
-    lds_store<n>(Wc + by, n, v);
+    lds_store<n>(Wy, n, v);
   }
   __syncthreads();
   // P2: interpolate along z -> values at the quadrature points; z-derivative part
-  if (act) {
-    lds_load<n>(Wc + bz, n2, u);
-    lds_load<n>(cf + bz, n2, v);
+  if (actz) {
+    lds_load<n>(Wz, n2, u);
+    lds_load<n>(Cz, n2, v);
     mvt<n, 1>(tab.S, u, w);
     mv<n, -1>(tab.Dt, w, g);
 #pragma unroll
     for (int s = 0; s < n; ++s) g[s] *= v[s];
     mvt<n, -1>(tab.Dt, g, r);
-    lds_store<n>(Wc + bz, n2, w);
-    lds_store<n>(Rc + bz, n2, r);
+    lds_store<n>(Wz, n2, w);
+    lds_store<n>(Rz, n2, r);
   }
   __syncthreads();
   // P3: x-derivative part
@@ -113,25 +113,25 @@ __device__ __forceinline__ void cell_pipeline_x(const bool act, const int pa, co
   }
   __syncthreads();
   // P4: y-derivative part, then S^T along y
-  if (act) {
-    lds_load<n>(Wc + by, n, w);
-    lds_load<n>(cf + by, n, v);
+  if (acty) {
+    lds_load<n>(Wy, n, w);
+    lds_load<n>(Cy, n, v);
     mv<n, -1>(tab.Dt, w, g);
 #pragma unroll
     for (int s = 0; s < n; ++s) g[s] *= v[s];
     mvt<n, -1>(tab.Dt, g, r);
-    lds_load<n>(Rc + by, n, v);
+    lds_load<n>(Ry, n, v);
 #pragma unroll
     for (int s = 0; s < n; ++s) r[s] += v[s];
     mv<n, 1>(tab.S, r, v);
-    lds_store<n>(Rc + by, n, v);
+    lds_store<n>(Ry, n, v);
   }
   __syncthreads();
   // P5: S^T along z; the coefficient buffer is free now (last read in P4)
-  if (act) {
-    lds_load<n>(Rc + bz, n2, u);
+  if (actz) {
+    lds_load<n>(Rz, n2, u);
     mv<n, 1>(tab.S, u, v);
-    lds_store<n>(Rc + bz, n2, v);
+    lds_store<n>(Rz, n2, v);
   }
   stage_next();
   __syncthreads();
@@ -146,16 +146,16 @@ __device__ __forceinline__ void cell_pipeline_x(const bool act, const int pa, co
     bool type;
     if (act) lds_store<n>(Rc + bx, 1, v);
     __syncthreads();
-    if (act && mask && hn_flag3<n, 1>(mask, pb, pa, type)) {
-      lds_load<n>(Rc + by, n, v);
+    if (acty && mask && hn_flag3<n, 1>(mask, pb, pa, type)) {
+      lds_load<n>(Ry, n, v);
       hn_pencil<n, T, true, true>(Wl, type, v);
-      lds_store<n>(Rc + by, n, v);
+      lds_store<n>(Ry, n, v);
     }
     __syncthreads();
-    if (act && mask && hn_flag3<n, 2>(mask, pa, pb, type)) {
-      lds_load<n>(Rc + bz, n2, v);
+    if (actz && mask && hn_flag3<n, 2>(mask, pa, pb, type)) {
+      lds_load<n>(Rz, n2, v);
       hn_pencil<n, T, true, true>(Wl, type, v);
-      lds_store<n>(Rc + bz, n2, v);
+      lds_store<n>(Rz, n2, v);
     }
     __syncthreads();
     if (act) {
@@ -248,6 +248,21 @@ apply_batches_x(const ApplyArgs<T> A, const Tables<T, n> tab) {
   T *Wc = Wb + lc * nd;
   T *Rc = Rb + lc * nd;
   const T *cf = Cb + lc * nd;
+  // Which y-pencil and which z-pencil of the chunk this thread owns.  The x-stage ownership (cell lc, pencil
+  // pen) is tied to the gather / scatter index runs and is conflict-free as it is (pencil bases 5 * lane).  In
+  // the y- and z-stages the natural ownership costs 2x / 1.5x LDS cycles in bank conflicts, so the host
+  // supplies a lane -> pencil map (A.perm, mfgpu_api.hip) under which the 32 lanes of a ds_read_b64 group and
+  // the 16 lanes of a ds_write_b64 group hit distinct banks.  Hanging-node kernels keep the natural map:
+  // their constraint flags are functions of the x-stage's (pa, pb).
+  int cy = lc, oy = lane_on ? lc * nd + pa + n2 * pb : -1;  // y-pencil (x = pa, z = pb), stride n
+  int cz = lc, oz = lane_on ? lc * nd + pa + n * pb : -1;   // z-pencil (x = pa, y = pb), stride n2
+  if (!HN && A.perm) {
+    const int qy = A.perm[tid], qz = A.perm[kBlock + tid];  // pencil id = cell * P + pencil, or 0xffff: idle lane
+    cy = qy / P;
+    oy = qy == 0xffff ? -1 : cy * nd + (qy % P) % n + n2 * ((qy % P) / n);
+    cz = qz / P;
+    oz = qz == 0xffff ? -1 : cz * nd + (qz % P) % n + n * ((qz % P) / n);
+  }
 
   // hipcc hoists the per-thread constants tid + j * 256 of every unrolled helper loop out of the batch
   // loop and keeps all of them live; an opaque copy of the thread index makes them temporaries
@@ -404,9 +419,11 @@ apply_batches_x(const ApplyArgs<T> A, const Tables<T, n> tab) {
         if (act) mask = A.cmask[(size_t)c0 + base + lc];
         any_mask = __syncthreads_or(mask != 0) != 0;
       }
-      cell_pipeline_x<n, T, HN>(act, pa, pb, mask, any_mask, U[k], IX[k], ua, Wc, Rc, cf, Wl, tab, [&]() {
-        if (cnt_next > 0) stage(cnt_next);
-      });
+      const bool acty = oy >= 0 && base + cy < ncell, actz = oz >= 0 && base + cz < ncell;
+      cell_pipeline_x<n, T, HN>(act, acty, actz, pa, pb, mask, any_mask, U[k], IX[k], ua, Wc, Rc, cf, Wb + oy, Rb + oy,
+                                Cb + oy, Wb + oz, Rb + oz, Cb + oz, Wl, tab, [&]() {
+                                  if (cnt_next > 0) stage(cnt_next);
+                                });
     }
     if (has_nb && ncell <= (KC - 1) * CH) {  // short batch (ragged meshes): no overlap
       load_src(Gn, SVn);

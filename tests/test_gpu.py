@@ -58,6 +58,7 @@ def test_vmult_matches_oracle(dim, p, n, nt, colored):
 
 KNOBS = [("MFGPU_X", "0", "apply_batches"), ("MFGPU_GROUPS", "0", "apply_batches_x"),
          ("MFGPU_GRID", "13", "apply_batches_x"),  # persistent grid that is no multiple of the 8 XCDs
+         ("MFGPU_NOPERM", "1", "apply_batches_x"),  # natural lane -> pencil ownership in the y- and z-stages
          ("MFGPU_LS", "1", "apply_batches_ls"),
          ("MFGPU_WAVE", "1", "apply_batches"), ("MFGPU_PLANE", "1", "apply_planes")]
 
