@@ -165,7 +165,7 @@ struct WaveSync {
 // in LDS.  stage_next() is called once, at the point where cf / lm are no longer needed.
 template <int dim, int n, typename T, bool HN, typename Sync, typename StageNext>
 __device__ __forceinline__ void cell_pipeline(const bool act, const int pa, const int pb, const unsigned mask,
-                                              const bool any_mask, const T *usrc, T *acc, T *Wc, T *Rc,
+                                              const bool any_mask, const T *usrc, double *acc, T *Wc, T *Rc,
                                               const T *cf, const uint16_t *lm, const T *Wl,
                                               const Tables<T, n> &tab, StageNext &&stage_next,
                                               const int dbg = 0, unsigned long long *pst = nullptr) {
@@ -320,11 +320,11 @@ __device__ __forceinline__ void cell_pipeline(const bool act, const int pa, cons
         lds_load<n>(Rc + bx, 1, v);
         if (mask && hn_flag3<n, 0>(mask, pa, pb, type)) hn_pencil<n, T, true>(Wl, type, v);
 #pragma unroll
-        for (int i = 0; i < n; ++i) lds_add(&acc[ix[i]], v[i]);
+        for (int i = 0; i < n; ++i) lds_add(&acc[ix[i]], (double)v[i]);
       }
     } else if (act) {
 #pragma unroll
-      for (int k = 0; k < n; ++k) if (!PDBG(16)) lds_add(&acc[iz[k]], v[k]); else asm volatile("" ::"v"(v[k]), "v"(iz[k]));
+      for (int k = 0; k < n; ++k) if (!PDBG(16)) lds_add(&acc[iz[k]], (double)v[k]); else asm volatile("" ::"v"(v[k]), "v"(iz[k]));
     }
     PSTAMP(7);
   } else {  // dim == 2
@@ -393,11 +393,11 @@ __device__ __forceinline__ void cell_pipeline(const bool act, const int pa, cons
         lds_load<n>(Rc + bx, 1, v);
         if (mask && hn_flag2<n, 0>(mask, pa, type)) hn_pencil<n, T, true>(Wl, type, v);
 #pragma unroll
-        for (int i = 0; i < n; ++i) lds_add(&acc[ix[i]], v[i]);
+        for (int i = 0; i < n; ++i) lds_add(&acc[ix[i]], (double)v[i]);
       }
     } else if (act) {
 #pragma unroll
-      for (int k = 0; k < n; ++k) if (!PDBG(16)) lds_add(&acc[iz[k]], v[k]); else asm volatile("" ::"v"(v[k]), "v"(iz[k]));
+      for (int k = 0; k < n; ++k) if (!PDBG(16)) lds_add(&acc[iz[k]], (double)v[k]); else asm volatile("" ::"v"(v[k]), "v"(iz[k]));
     }
     if (stage_next()) Sync::sync();  // Cb last read in P2, Lb at the chunk start
   }

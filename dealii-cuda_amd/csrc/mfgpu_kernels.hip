@@ -51,15 +51,16 @@ apply_batches(const ApplyArgs<T> A, const Tables<T, n> tab) {
   constexpr int CHND = CH * nd;
   static_assert(CH >= 1, "a cell's pencils must fit into one thread group");
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
-  T *usrc = reinterpret_cast<T *>(smem_raw);
-  T *acc = usrc + A.nb_max;
+  // the accumulator is double also in float builds (ds_add_f32 is slow on gfx950, see apply_batches_x)
+  double *acc = reinterpret_cast<double *>(smem_raw);
+  T *usrc = reinterpret_cast<T *>(acc + A.nb_max);
   const int tid = threadIdx.x;
   const int grp = 0;
   const int gtid = tid;
-  T *Wb = acc + A.nb_max + grp * 3 * CHND;
+  T *Wb = usrc + A.nb_max + grp * 3 * CHND;
   T *Rb = Wb + CHND;
   T *Cb = Rb + CHND;     // folded coefficient of the cells in flight
-  T *Wl = acc + A.nb_max + NG * 3 * CHND;  // hanging-node weights (HN only), broadcast reads
+  T *Wl = usrc + A.nb_max + NG * 3 * CHND;  // hanging-node weights (HN only), broadcast reads
   uint16_t *Lb = reinterpret_cast<uint16_t *>(Wl + n2) + grp * CHND;  // local->batch dof map of the cells in flight
 
   // Workgroup loops over batches b, b + gridDim.x, ... of [batch0, batch_end) (grid = resident
@@ -178,7 +179,7 @@ apply_batches(const ApplyArgs<T> A, const Tables<T, n> tab) {
       const bool con = (G[j] >> 31) != 0;
       if (t < nb) {
         usrc[t] = con ? T(0) : SV[j];
-        acc[t] = T(0);
+        acc[t] = 0.0;
         const bool owner = TWOPASS ? (t < nint) : !(F[j] & kFlagAdd);
         if (con && owner) {
           T *d = A.dst + (G[j] & 0x7fffffffu);
@@ -277,9 +278,9 @@ apply_batches(const ApplyArgs<T> A, const Tables<T, n> tab) {
         for (int j = 0; j < kGU; ++j) {
           const int t = tid + j * kBlock;
           if (t < nint) {
-            if (!(G[j] >> 31)) A.dst[G[j]] = A.add ? old[j] + acc[t] : acc[t];
+            if (!(G[j] >> 31)) A.dst[G[j]] = A.add ? old[j] + (T)acc[t] : (T)acc[t];
           } else if (t < nb) {
-            halo[t - nint] = acc[t];  // constrained shared dofs: value ignored by reduce_shared
+            halo[t - nint] = (T)acc[t];  // constrained shared dofs: value ignored by reduce_shared
           }
         }
       }
@@ -292,7 +293,7 @@ apply_batches(const ApplyArgs<T> A, const Tables<T, n> tab) {
 #pragma unroll
       for (int j = 0; j < kGU; ++j) {
         const int t = tid + j * kBlock;
-        if (t < nb && !(G[j] >> 31)) A.dst[G[j]] = ((F[j] & kFlagAdd) || A.add) ? old[j] + acc[t] : acc[t];
+        if (t < nb && !(G[j] >> 31)) A.dst[G[j]] = ((F[j] & kFlagAdd) || A.add) ? old[j] + (T)acc[t] : (T)acc[t];
       }
     }
     STAMP(15);
@@ -726,7 +727,8 @@ static size_t lds_bytes_t(uint32_t nb_max, bool wave) {
   constexpr int nd = (dim == 3) ? n * n * n : n * n;
   const int NG = 1;
   const int CH = (wave ? 64 : 256) / (nd / n);
-  return (size_t)(2 * nb_max + NG * 3 * CH * nd + n * n) * sizeof(T) + (size_t)NG * CH * nd * sizeof(uint16_t);
+  return (size_t)nb_max * sizeof(double) + (size_t)(nb_max + NG * 3 * CH * nd + n * n) * sizeof(T) +
+         (size_t)NG * CH * nd * sizeof(uint16_t);
 }
 
 template <int dim, int n, typename T, bool HN, bool TP, bool WV>

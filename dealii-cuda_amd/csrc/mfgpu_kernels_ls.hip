@@ -87,9 +87,9 @@ apply_batches_ls(const ApplyArgs<T> A, const Tables<T, n> tab) {
   constexpr int PFL = (CHND + kLsLoader - 1) / kLsLoader;
   static_assert(CH >= 1 && CH <= kLsLoader, "chunk masks are staged by one loader lane per cell");
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
-  T *usrc = reinterpret_cast<T *>(smem_raw);
-  T *acc = usrc + A.nb_max;
-  T *Wb = acc + A.nb_max;
+  double *acc = reinterpret_cast<double *>(smem_raw);  // double also in float builds (ds_add_f32 is slow on gfx950)
+  T *usrc = reinterpret_cast<T *>(acc + A.nb_max);
+  T *Wb = usrc + A.nb_max;
   T *Rb = Wb + CHND;
   T *Cb = Rb + CHND;
   T *Wl = Cb + CHND;
@@ -162,13 +162,13 @@ apply_batches_ls(const ApplyArgs<T> A, const Tables<T, n> tab) {
     // dofs, summed by reduce_shared); clears the accumulator for the next batch
     auto scatter = [&](const uint32_t (&g)[kGL], const Meta &m) {
       const int l = lane();
-      T *al = acc + l;
+      double *al = acc + l;
       T *hl = A.halo + m.hoff + l - m.nint;
 #pragma unroll
       for (int j = 0; j < kGL; ++j) {
         if (l < (int)A.nb_max - j * kLsLoader) {
-          const T v = al[j * kLsLoader];
-          al[j * kLsLoader] = T(0);
+          const T v = (T)al[j * kLsLoader];
+          al[j * kLsLoader] = 0.0;
           if (l < m.nint - j * kLsLoader) {
             if (!(g[j] >> 31)) {
               T *d = A.dst + g[j];
@@ -237,7 +237,7 @@ apply_batches_ls(const ApplyArgs<T> A, const Tables<T, n> tab) {
     for (int j = 0; j < kGL; ++j) {
       Gn[j] = 0;
       const int t = lt + j * kLsLoader;
-      if (t < (int)A.nb_max) acc[t] = T(0);
+      if (t < (int)A.nb_max) acc[t] = 0.0;
     }
     if (HN)
       for (int t = lt; t < n2; t += kLsLoader) Wl[t] = A.hn_weights[t];
@@ -325,7 +325,8 @@ static size_t ls_lds_bytes(uint32_t nb_max) {
   constexpr int nd = (dim == 3) ? n * n * n : n * n;
   constexpr int CH = kLsCompute / (nd / n);
   constexpr int CHND = CH * nd;
-  return (size_t)(2 * nb_max + 3 * CHND + n * n) * sizeof(T) + (size_t)((CHND + 1) & ~1) * sizeof(uint16_t) +
+  return (size_t)nb_max * sizeof(double) + (size_t)(nb_max + 3 * CHND + n * n) * sizeof(T) +
+         (size_t)((CHND + 1) & ~1) * sizeof(uint16_t) +
          (size_t)(CH + 2 + 4) * sizeof(uint32_t);
 }
 
