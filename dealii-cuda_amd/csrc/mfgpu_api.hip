@@ -760,5 +760,10 @@ int mfgpu_device_synchronize(void) {
   HIP_TRY(hipDeviceSynchronize());
   return 0;
 }
+int mfgpu_device_memory_info(size_t *free_bytes, size_t *total_bytes) {
+  if (!free_bytes || !total_bytes) return MFGPU_EINVAL;
+  HIP_TRY(hipMemGetInfo(free_bytes, total_bytes));
+  return 0;
+}
 
 }  // extern "C"

@@ -44,7 +44,7 @@ SYMBOLS = [
     "mfgpu_vec_dot", "mfgpu_vec_l2_norm", "mfgpu_vec_add_and_dot", "mfgpu_vec_all_zero", "mfgpu_profile_enable", "mfgpu_profile_read",
     "mfgpu_plan_create", "mfgpu_plan_destroy", "mfgpu_plan_array_u32", "mfgpu_plan_lmap", "mfgpu_plan_bflags",
     "mfgpu_vec_alloc", "mfgpu_vec_free", "mfgpu_vec_fill", "mfgpu_vec_from_host", "mfgpu_vec_to_host",
-    "mfgpu_device_synchronize", "mfgpu_mesh_create_uniform", "mfgpu_mesh_create_adaptive", "mfgpu_mesh_create_from_leaves",
+    "mfgpu_device_synchronize", "mfgpu_device_memory_info", "mfgpu_mesh_create_uniform", "mfgpu_mesh_create_adaptive", "mfgpu_mesh_create_from_leaves",
     "mfgpu_mesh_cell_levels", "mfgpu_mesh_destroy",
     "mfgpu_mesh_desc", "mfgpu_mesh_dof_coords", "mfgpu_mesh_interface_dofs",
 ]
@@ -70,6 +70,7 @@ def lib():
         L.mfgpu_destroy.argtypes = [C.c_void_p]
         L.mfgpu_destroy.restype = None
         L.mfgpu_plan_stats.argtypes = [C.c_void_p, C.POINTER(C.c_uint64)]
+        L.mfgpu_device_memory_info.argtypes = [C.POINTER(C.c_size_t), C.POINTER(C.c_size_t)]
         L.mfgpu_kernel_name.argtypes = [C.c_void_p]
         L.mfgpu_kernel_name.restype = C.c_char_p
         L.mfgpu_compute_inverse_diagonal.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p]
@@ -457,3 +458,10 @@ def _ptr(v):
 
 def synchronize():
     _check(lib().mfgpu_device_synchronize())
+
+
+def device_memory_info():
+    """(free, total) bytes of the current device"""
+    f, t = C.c_size_t(), C.c_size_t()
+    _check(lib().mfgpu_device_memory_info(C.byref(f), C.byref(t)))
+    return f.value, t.value

@@ -177,7 +177,10 @@ int mfgpu_vec_free(void *dev);
 int mfgpu_vec_fill(void *dev, size_t n, int number_type, double value, void *stream); /* vec_init, gpu_vec.cu:281-291 */
 int mfgpu_vec_from_host(void *dev, const void *host, size_t n, int number_type);
 int mfgpu_vec_to_host(void *host, const void *dev, size_t n, int number_type);
-int mfgpu_device_synchronize(void); /* bmop.cu:148 */
+int mfgpu_device_synchronize(void);
+/* free / total bytes of the current device (hipMemGetInfo): lets callers and tests check that
+ * mfgpu_destroy / mfgpu_vec_free return everything mfgpu_create / mfgpu_vec_alloc took              */
+int mfgpu_device_memory_info(size_t *free_bytes, size_t *total_bytes); /* bmop.cu:148 */
 
 /* ---- deal.II stand-in for the setup side (host only) --------------------------------------
  * Produces what Triangulation + DoFHandler + ConstraintMatrix + FEValues + ShapeInfo hand to

@@ -374,3 +374,40 @@ def test_slab_decomposition_with_the_gpu_operator(p, n, world):
         ref = o.vmult(od, x)
         assert rel(acc, ref) <= 1e-12
         x = acc
+
+
+def test_create_destroy_returns_all_device_memory():
+    """mfgpu_destroy / mfgpu_vec_free give back everything mfgpu_create / mfgpu_vec_alloc / the first vmult,
+    diagonal and reduction took: repeated set-up and tear-down of operators of every kernel family must not
+    shrink the free device memory (hipMemGetInfo)."""
+    from util import deformed_oracle_desc
+
+    def cycle():
+        for kind in ("uniform", "adaptive", "colored", "2d", "general"):
+            if kind == "general":
+                desc, keep = desc_from_oracle(deformed_oracle_desc(2, 4))
+            else:
+                keep = (mf.Mesh.adaptive(3, 2, 4) if kind == "adaptive" else
+                        mf.Mesh.uniform(2, 3, 20) if kind == "2d" else mf.Mesh.uniform(3, 4, 8))
+                desc = keep.desc
+                if kind == "colored":
+                    desc.flags |= mf.COLORED_SCATTER
+            op = mf.Operator(desc, keep)
+            n = op.n()
+            a, b = mf.DeviceVector(n), mf.DeviceVector(n)
+            a.fill(1.0)
+            op.vmult(b, a)
+            op.compute_inverse_diagonal(a)
+            b.dot(a)
+            mf.synchronize()
+            op.clear()
+            del a, b, op
+
+    cycle()                       # first use allocates the per-device reduction scratch (kept by design)
+    mf.synchronize()
+    free0, total = mf.device_memory_info()
+    for _ in range(5):
+        cycle()
+    mf.synchronize()
+    free1, _ = mf.device_memory_info()
+    assert free0 - free1 <= 8 << 20, (free0, free1)   # allocator granularity only, no growth per cycle
