@@ -95,7 +95,9 @@ typedef struct mfgpu_desc {
 /* ---- operator (replaces LaplaceOperatorGpu::reinit / vmult / vmult_add / clear) -------- */
 
 /* laplace_operator_gpu.h:120-151 (reinit): copies the description to the device, builds the
- * batch/colour plan, folds coefficient * J0^2 * JxW.  Uses the current HIP device.           */
+ * batch plan, folds coefficient * J0^2 * JxW (general geometry: the symmetric coefficient * JxW * J^-1 J^-T per
+ * quadrature point).  Uses the current HIP device.  Fails (MFGPU_EHIP) if no HIP device / kernel image is
+ * available: there is no CPU fallback.                                                        */
 int mfgpu_create(const mfgpu_desc *desc, mfgpu_handle **out);
 
 /* laplace_operator_gpu.h:216-223: dst = A src.  dst, src: device vectors of n_dofs Numbers.
