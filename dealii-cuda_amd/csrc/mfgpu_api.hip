@@ -32,6 +32,10 @@ struct mfgpu_handle {
   uint16_t *d_lmap = nullptr;
   uint16_t *d_lmapx = nullptr;
   uint16_t *d_perm = nullptr;  // apply_batches_x: bank-conflict-free lane -> pencil maps of the y- and z-stage
+  // apply_planes3: fixed-size per-batch records (see ApplyArgs)
+  uint4 *d_metap = nullptr;
+  uint32_t *d_bdofsp = nullptr, *d_idxp = nullptr;
+  void *d_coefp = nullptr;
   void *d_coef = nullptr;
   uint32_t *d_cmask = nullptr, *d_orphans = nullptr;
   void *d_hnw = nullptr;
@@ -52,6 +56,7 @@ struct mfgpu_handle {
   bool ls = false;        // loader / compute specialised cell loop (apply_batches_ls)
   bool xk = false;        // 3D two-pass kernel for three workgroups per CU (apply_batches_x)
   bool gk = false;        // general-Jacobian kernel (apply_batches_g)
+  bool pk = false;        // plane-per-thread kernel (apply_planes3): 3D uniform-Jacobian default for p = 2..4
   bool wave = false;      // wave-granular cell phase (apply_batches<..., WAVE = true>)
   // profiling
   bool prof = false;
@@ -151,6 +156,40 @@ int create_typed(mfgpu_handle *h, const mfgpu_desc &d) {
       for (size_t i = 0; i < n; ++i) lx[r * np + i] = P.lmap[r * n + i];
     if ((rc = dev_upload(&h->d_lmapx, lx.data(), lx.size() * 2, acct))) return rc;
   }
+  if (h->pk) {
+    // Fixed-size per-batch records of apply_planes3: metadata, the dof list padded to p_kgu * 64 entries with its
+    // last entry, and per task (cell c, plane k) the n*n batch-local ids of the xy-plane z = k as byte offsets
+    // (id * 8) packed two per word, stored [word][task] so that a wave reads consecutive words.
+    const int n = P.n, n2 = n * n, NT = p_cells_per_wave(n) * n, NIW = (n2 + 1) / 2, NB = p_kgu(n) * 64;
+    const size_t nbat = P.batch_cell_off.size() - 1;
+    // (the tasks of cells a ragged batch does not have point at the batch array's last slot, which is never a dof:
+    // the planner keeps every batch below NB dofs)
+    const uint32_t dummy = 8u * (uint32_t)(NB - 1);
+    std::vector<uint32_t> meta(4 * nbat), bd((size_t)NB * nbat), ix((size_t)NIW * NT * nbat, dummy | (dummy << 16));
+    for (size_t b = 0; b < nbat; ++b) {
+      const uint32_t c0 = P.batch_cell_off[b], nc = P.batch_cell_off[b + 1] - c0;
+      const uint32_t d0 = P.batch_dof_off[b], nbd = P.batch_dof_off[b + 1] - d0;
+      if ((int)nc * n > NT || (int)nbd >= NB) {
+        set_error("internal: batch exceeds the plane kernel's slots");
+        return MFGPU_EINVAL;
+      }
+      meta[4 * b + 0] = nc;
+      meta[4 * b + 1] = nbd;
+      meta[4 * b + 2] = P.batch_nint[b];
+      meta[4 * b + 3] = P.halo_off[b];
+      for (int t = 0; t < NB; ++t) bd[b * NB + t] = P.bdofs[d0 + ((uint32_t)t < nbd ? (uint32_t)t : nbd - 1)];
+      for (uint32_t c = 0; c < nc; ++c)
+        for (int k = 0; k < n; ++k)
+          for (int i = 0; i < n2; ++i) {
+            const uint32_t off = 8u * P.lmap[(size_t)(c0 + c) * P.nd + i + n2 * k];
+            uint32_t &w = ix[(b * NIW + i / 2) * NT + c * n + k];
+            w = (i & 1) ? ((w & 0xffffu) | (off << 16)) : ((w & 0xffff0000u) | off);
+          }
+    }
+    if ((rc = dev_upload(&h->d_metap, meta.data(), meta.size() * 4, acct))) return rc;
+    if ((rc = dev_upload(&h->d_bdofsp, bd.data(), bd.size() * 4, acct))) return rc;
+    if ((rc = dev_upload(&h->d_idxp, ix.data(), ix.size() * 4, acct))) return rc;
+  }
   if ((rc = dev_upload(&h->d_orphans, P.orphans.data(), P.orphans.size() * 4, acct))) return rc;
   if (h->twopass) {
     if ((rc = dev_upload(&h->d_batch_nint, P.batch_nint.data(), P.batch_nint.size() * 4, acct))) return rc;
@@ -168,7 +207,11 @@ int create_typed(mfgpu_handle *h, const mfgpu_desc &d) {
       if ((rc = dev_upload(&h->d_s_off, P.s_off.data(), P.s_off.size() * 4, acct))) return rc;
       if ((rc = dev_upload(&h->d_s_idx, P.s_idx.data(), P.s_idx.size() * 4, acct))) return rc;
     }
-    const size_t hb = (size_t)P.halo_off.back() * sizeof(T);
+    if (h->pk && P.halo_off.back() + 64ull >= (1ull << 29)) {
+      set_error("halo buffer too large for 32-bit byte offsets");
+      return MFGPU_EUNSUPPORTED;
+    }
+    const size_t hb = ((size_t)P.halo_off.back() + (h->pk ? 64 : 0)) * sizeof(T);  // + apply_planes3's store sink
     if (hb) {
       HIP_TRY(hipMalloc(&h->d_halo, hb));
       HIP_TRY(hipMemset(h->d_halo, 0, hb));
@@ -222,6 +265,47 @@ int create_typed(mfgpu_handle *h, const mfgpu_desc &d) {
   if (e != hipSuccess) {
     set_error(std::string("coefficient fold: ") + hipGetErrorString(e));
     return MFGPU_EHIP;
+  }
+  if (h->pk) {
+    // the folded coefficient again, per batch [row y + n z][task]: the layout of stage B of apply_planes3
+    // (d_coef in plan cell order stays: the diagonal kernel reads it)
+    const int n = P.n, NT = p_cells_per_wave(n) * n;
+    const size_t nbat = P.batch_cell_off.size() - 1, total = nbat * (size_t)(n * n) * NT;
+    std::vector<uint32_t> cb(ncell), cp(ncell);
+    for (size_t b = 0; b < nbat; ++b)
+      for (uint32_t c = P.batch_cell_off[b]; c < P.batch_cell_off[b + 1]; ++c) {
+        cb[c] = (uint32_t)b;
+        cp[c] = c - P.batch_cell_off[b];
+      }
+    uint32_t *t_cb = nullptr, *t_cp = nullptr;
+    size_t tmp2 = 0;
+    rc = dev_upload(&t_cb, cb.data(), ncell * 4, tmp2);
+    if (!rc) rc = dev_upload(&t_cp, cp.data(), ncell * 4, tmp2);
+    if (!rc) {
+      hipError_t e2 = hipMalloc(&h->d_coefp, total * sizeof(T));
+      if (e2 == hipSuccess) {
+        acct += total * sizeof(T);
+        e2 = hipMemset(h->d_coefp, 0, total * sizeof(T));
+      }
+      if (e2 == hipSuccess)
+        e2 = relayout_coef_launch<T>((T *)h->d_coefp, (const T *)h->d_coef, t_cb, t_cp, ncell * nd, n, nullptr);
+      if (e2 == hipSuccess) e2 = hipDeviceSynchronize();
+      if (e2 != hipSuccess) {
+        set_error(std::string("coefficient relayout: ") + hipGetErrorString(e2));
+        rc = e2 == hipErrorOutOfMemory ? MFGPU_ENOMEM : MFGPU_EHIP;
+      }
+    }
+    hipFree(t_cb);
+    hipFree(t_cp);
+    if (rc) return rc;
+    ApplyArgs<T> dummy{};
+    int per_cu = 0, dev = 0;
+    hipDeviceProp_t prop;
+    HIP_TRY(p_launch<T>(P.n, dummy, nullptr, nullptr, 0, nullptr, true, &h->lds, &per_cu));
+    HIP_TRY(hipGetDevice(&dev));
+    HIP_TRY(hipGetDeviceProperties(&prop, dev));
+    h->max_grid = (uint32_t)(per_cu < 1 ? 1 : per_cu) * (uint32_t)prop.multiProcessorCount;
+    return 0;
   }
   if (h->plane) {
     ApplyArgs<T> dummy{};
@@ -321,6 +405,11 @@ int vmult_typed(mfgpu_handle *h, void *dst, const void *src, hipStream_t st, int
   a.lmap = h->d_lmap;
   a.lmapx = h->d_lmapx;
   a.perm = h->d_perm;
+  a.metap = h->d_metap;
+  a.bdofsp = h->d_bdofsp;
+  a.idxp = h->d_idxp;
+  a.coefp = (const T *)h->d_coefp;
+  a.halo_slots = P.halo_off.back();
   a.coef = (const T *)h->d_coef;
   a.cmask = h->d_cmask;
   a.hn_weights = (const T *)h->d_hnw;
@@ -355,7 +444,10 @@ int vmult_typed(mfgpu_handle *h, void *dst, const void *src, hipStream_t st, int
       HIP_TRY(hipEventRecord(h->ev[h->ev_used], st));
     }
     a.batch_end = a.batch0 + nbat;
-    if (h->gk)
+    if (h->pk)
+      HIP_TRY(p_launch<T>(P.n, a, h->S.data(), h->Dt.data(), nbat < h->max_grid ? nbat : h->max_grid, st, false,
+                          nullptr, nullptr));
+    else if (h->gk)
       HIP_TRY(g_launch<T>(P.n, a, h->S.data(), h->Dt.data(), h->hn, nbat < h->max_grid ? nbat : h->max_grid, st, false,
                           nullptr, nullptr));
     else if (h->xk)
@@ -507,8 +599,25 @@ int mfgpu_create(const mfgpu_desc *desc, mfgpu_handle **out) {
     h->gk = true;
     h->xk = h->wave = h->plane = h->ls = false;
   }
+  // apply_planes3: 3D, uniform-Jacobian path, conforming meshes, two-pass mode, p = 2..4 (desc.kernel 0 or 3)
+  h->pk = d.dim == 3 && !general && !hn && !(d.flags & MFGPU_COLORED_SCATTER) && d.degree >= 2 && d.degree <= 4 &&
+          d.n_dofs < (1u << 29) &&  // vectors are addressed base + 32-bit byte offset
+          (d.kernel == MFGPU_KERNEL_AUTO || d.kernel == MFGPU_KERNEL_PLANES) && !h->wave && !h->plane && !h->ls;
+  if (d.kernel == MFGPU_KERNEL_PLANES && !h->pk) {
+    set_error("MFGPU_KERNEL_PLANES needs a 3D conforming uniform-Jacobian mesh, two-pass mode and degree 2..4");
+    delete h;
+    return MFGPU_EUNSUPPORTED;
+  }
+  if (d.kernel == MFGPU_KERNEL_PENCILS) h->xk = false;
+  PlanLimits lim;
+  if (h->pk) {
+    h->xk = false;
+    lim.max_cells = (uint32_t)p_cells_per_wave(d.degree + 1);
+    lim.max_dofs = (uint32_t)p_kgu(d.degree + 1) * 64u - 1u;  // the batch array's last slot stays free (idle tasks)
+    lim.slot_align = 64;
+  }
   // apply_batches_x unrolls 4 chunks at p=3 (64-cell batches = 13^3 dofs like p=4); everything else 3
-  int rc = build_plan(dplan, h->plan, (h->xk && d.degree == 3) ? 4u : 3u);
+  int rc = build_plan(dplan, h->plan, (h->xk && d.degree == 3) ? 4u : 3u, h->pk ? &lim : nullptr);
   if (rc) {
     delete h;
     return rc;
@@ -551,6 +660,10 @@ void mfgpu_destroy(mfgpu_handle *h) {
   hipFree(h->d_lmap);
   hipFree(h->d_lmapx);
   hipFree(h->d_perm);
+  hipFree(h->d_metap);
+  hipFree(h->d_bdofsp);
+  hipFree(h->d_idxp);
+  hipFree(h->d_coefp);
   hipFree(h->d_constrained);
   hipFree(h->d_tab2);
   hipFree(h->d_coef);
@@ -621,7 +734,7 @@ int mfgpu_plan_stats(const mfgpu_handle *h, uint64_t s[8]) {
 
 const char *mfgpu_kernel_name(const mfgpu_handle *h) {
   if (!h) return "";
-  return h->gk ? "apply_batches_g" : h->xk ? "apply_batches_x" : h->ls ? "apply_batches_ls" : h->plane ? "apply_planes" : "apply_batches";
+  return h->pk ? "apply_planes3" : h->gk ? "apply_batches_g" : h->xk ? "apply_batches_x" : h->ls ? "apply_batches_ls" : h->plane ? "apply_planes" : "apply_batches";
 }
 
 int mfgpu_profile_enable(mfgpu_handle *h, int on) {

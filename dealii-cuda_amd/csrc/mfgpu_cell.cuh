@@ -135,7 +135,17 @@ __device__ __forceinline__ void lds_add(T *p, T v) {
     }                                                                                     \
   } while (0)
 #define DBG(bit) (A.dbg & (bit))
+// constant-rate (100 MHz) counter next to a cycle stamp: in-kernel clock = d(s_memtime) / d(s_memrealtime) * 100 MHz
+#define RSTAMP(k)                                                                         \
+  do {                                                                                    \
+    if (A.stamps && threadIdx.x == 0) {                                                   \
+      unsigned long long t_;                                                              \
+      asm volatile("s_memrealtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_)::"memory");       \
+      A.stamps[(size_t)b * 16 + (k)] = t_;                                                \
+    }                                                                                     \
+  } while (0)
 #else
+#define RSTAMP(k)
 #define STAMP(k)
 #define DBG(bit) 0
 #endif

@@ -18,6 +18,17 @@ inline int ipow(int a, int e) {
   return r;
 }
 
+// ---- apply_planes3 (mfgpu_kernels_p.hip): a wave owns 64 / n cells (n lanes per cell); a batch's dof list passes
+// through p_kgu(n) 64-lane register slots; cells of the LDS transpose arrays are p_cell_stride(n) values apart
+// (stride = n mod 32: the 16-lane store groups and 32-lane load groups of the yz-plane stage hit distinct banks)
+constexpr int p_cells_per_wave(int n) { return 64 / n; }
+constexpr int p_kgu(int n) { return n == 2 ? 2 : n == 3 ? 5 : n == 4 ? 11 : n == 5 ? 17 : n == 6 ? 24 : 35; }
+constexpr int p_cell_stride(int n) {
+  int s = n * n * n;
+  while ((s & 31) != (n & 31)) ++s;
+  return s;
+}
+
 constexpr uint8_t kFlagConstrained = 1;  // batch dof is a constrained row (identity)
 constexpr uint8_t kFlagAdd = 2;          // batch is NOT the first toucher: dst += (else dst =)
 
@@ -49,9 +60,18 @@ struct Plan {
   uint64_t n_first = 0, n_add = 0;
 };
 
+// Batch limits a cell-loop kernel imposes on the planner (0 = derive from the description, see
+// default_batch_limits): apply_planes3 processes a batch in one pass of one wave.
+struct PlanLimits {
+  uint32_t max_cells = 0, max_dofs = 0;
+  // > 0: the interior (stored-by-the-cell-loop) dofs of every batch fill whole slots of this many entries and
+  // contain no constrained dof; the rest takes the pass-2 route; halo regions are padded to whole slots
+  uint32_t slot_align = 0;
+};
+
 // Build the plan from a description (validates it).  Returns 0 or MFGPU_E*.
 // max_chunks: chunks of cells per batch the cell-loop kernel unrolls (3; apply_batches_x at p=3: 4)
-int build_plan(const mfgpu_desc &d, Plan &plan, uint32_t max_chunks = 3);
+int build_plan(const mfgpu_desc &d, Plan &plan, uint32_t max_chunks = 3, const PlanLimits *limits = nullptr);
 
 // Derive the kernel's 1D tables from the reference-layout tables T[dof*n+q]:
 //   S[i*n+q]  = shape_values (interpolation nodal -> quadrature points)

@@ -17,6 +17,12 @@ struct ApplyArgs {
   const uint16_t *lmap;
   const uint16_t *lmapx;  // apply_batches_x: x-pencil index runs padded to 32-bit words, or nullptr
   const uint16_t *perm;   // apply_batches_x: [2][256] lane -> pencil id of the y- and the z-stage, or nullptr (natural)
+  // apply_planes3: fixed-size per-batch records (nullptr otherwise)
+  const uint4 *metap;      // {cells, dofs, interior dofs, first halo slot}
+  const uint32_t *bdofsp;  // [p_kgu(n) * 64] dof list, padded with its last entry
+  const uint32_t *idxp;    // [(n*n+1)/2 words][NT tasks] packed 16-bit byte offsets into the batch array
+  const T *coefp;          // [n*n rows][NT tasks] folded coefficient
+  uint32_t halo_slots;     // halo[halo_slots .. +64) is the sink of the padding slots' stores
   const T *coef;          // folded a*J0^2*JxW (apply_batches_g: the 6 entries of a*JxW*J*J^T), plan cell order
   const uint32_t *cmask;  // plan cell order, or nullptr
   const T *hn_weights;    // [n*n] W[i*n+j] (device), or nullptr
@@ -64,6 +70,13 @@ hipError_t plane_launch(int n, const ApplyArgs<T> &a, const double *S, const dou
 template <typename T>
 hipError_t x_launch(int n, const ApplyArgs<T> &a, const double *S, const double *Dt, bool hn, uint32_t grid,
                     hipStream_t st, bool configure_only, size_t *lds_out, int *occupancy);
+// plane-per-thread cell loop (mfgpu_kernels_p.hip; 3D, two-pass mode, uniform-Jacobian path) and its setup relayout
+template <typename T>
+hipError_t p_launch(int n, const ApplyArgs<T> &a, const double *S, const double *Dt, uint32_t grid, hipStream_t st,
+                    bool configure_only, size_t *lds_out, int *occupancy);
+template <typename T>
+hipError_t relayout_coef_launch(T *out, const T *in, const uint32_t *cell_batch, const uint32_t *cell_pos,
+                                size_t total, int n, hipStream_t st);
 // general-Jacobian cell loop (mfgpu_kernels_g.hip; 3D, two-pass mode, conforming meshes) and its setup fold
 template <typename T>
 hipError_t g_launch(int n, const ApplyArgs<T> &a, const double *S, const double *Dt, bool hn, uint32_t grid,

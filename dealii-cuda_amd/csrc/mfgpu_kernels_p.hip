@@ -1,0 +1,500 @@
+// 3D cell-loop kernel, two-pass scatter mode, uniform-Jacobian path: a thread owns a 2D PLANE of a cell.
+//
+// Why (profiles/r01_notes.md, profiles/r02_notes.md): the pencil kernels (apply_batches, apply_batches_x) move every
+// cell value through LDS ten times (7 barrier-separated transposes + coefficient staging) and are bound by that
+// chain at 2-3 waves per SIMD.  Here a thread holds n x n values in registers, so two of the three tensor
+// directions are register mat-vecs and a cell needs TWO LDS transposes of two arrays:
+//
+//   stage A (xy-plane, nodal z = k):   t = S_y u,  a = S_x t,  b = D_x a                     -> LDS (a, b)
+//   stage B (yz-plane, quad  x = k):   gx = S_z b;  v = S_z a;  gy = D_y v;  gz = D_z v
+//                                      r  = D_y^T (c gy) + D_z^T (c gz);  r' = S_z^T r;  t' = S_z^T (c gx)
+//                                                                                            -> LDS (r', t') in place
+//   stage C (xy-plane, nodal z = k):   out = S_y^T S_x^T (r' + D_x^T t')                      -> batch accumulator
+//
+// i.e. the x-derivative is taken BEFORE the z-interpolation (they commute), so all three gradient components meet
+// the coefficient in ONE layout: the coefficient goes straight from HBM into registers (stored per batch as
+// [n*n rows][tasks], coalesced), never through LDS.  14 contractions per cell (reference: 18, tensor_ops.cuh:179-261;
+// pencil kernels: 12) for 5.5 LDS stores per value instead of 10.
+//
+// One wave owns CW = 64 / n cells (n lanes per cell); both transposes are cell-local, hence wave-local: no
+// s_barrier in the cell phase.  One workgroup = ONE wave = one batch (<= CW cells) in this version: the gather /
+// scatter staging is wave-local too and a CU runs four independent workgroups, one per SIMD, each with up to 512
+// registers.  Everything a batch needs from HBM (dof list, source values, index runs, coefficient rows) is in
+// flight one batch ahead (the dof list two), issued unconditionally at the top of the iteration and consumed
+// after ONE wait at its end, before any store of the iteration is issued (vmcnt is in-order and counts stores).
+//
+// Algebra per cell: fee_gpu.cuh:219-284 (uniform-Jacobian branch), tensor_ops.cuh:179-261;
+// gather / scatter: fee_gpu.cuh:323-363; constrained rows: constraint_handler_gpu.cu:247-289.
+#include <hip/hip_runtime.h>
+
+#include "mfgpu_cell.cuh"
+#include "mfgpu_kernels.h"
+
+namespace mfgpu {
+
+namespace {
+
+template <typename U>
+__device__ __forceinline__ U nt_load(const U *p) { return __builtin_nontemporal_load(p); }
+
+// strided view of a register plane: line `o` along direction DIR (0: fast index, 1: slow index)
+template <int n, int DIR, typename T>
+__device__ __forceinline__ void get_line(const T (&p)[n * n], int o, T (&l)[n]) {
+#pragma unroll
+  for (int i = 0; i < n; ++i) l[i] = p[DIR == 0 ? i + n * o : o + n * i];
+}
+template <int n, int DIR, typename T>
+__device__ __forceinline__ void set_line(T (&p)[n * n], int o, const T (&l)[n]) {
+#pragma unroll
+  for (int i = 0; i < n; ++i) p[DIR == 0 ? i + n * o : o + n * i] = l[i];
+}
+
+}  // namespace
+
+// Only LDS instructions may cross: pins a global memory operation between two compute steps (the
+// scheduler would otherwise issue all of them first), while the next step's LDS reads may still be hoisted
+#define MFGPU_PIN_VMEM() __builtin_amdgcn_sched_barrier(0x380)
+
+template <int n, typename T, bool ADD>
+__global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(1, 1)))
+apply_planes3(const ApplyArgs<T> A, const Tables<T, n> tab) {
+  constexpr int n2 = n * n;
+  constexpr int CW = p_cells_per_wave(n);  // cells per wave
+  constexpr int NT = CW * n;               // tasks (active lanes) of a full batch
+  constexpr int KGU = p_kgu(n);            // 64-lane slots of a batch's dof list
+  constexpr int SA = p_cell_stride(n);     // padded cell stride of the transpose arrays
+  constexpr int NIW = (n2 + 1) / 2;        // 32-bit words of a task's packed index run
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+  double *ua = reinterpret_cast<double *>(smem_raw);  // gathered source values, then the accumulator
+  T *Aw = reinterpret_cast<T *>(ua + KGU * 64);       // CW cells + one scratch cell for the idle lanes
+  T *Bw = Aw + (CW + 1) * SA;
+
+  const int lane = threadIdx.x;
+  // The idle lanes (NT .. 63) and the tasks of cells a ragged batch does not have run the same instruction stream on
+  // harmless data: the idle lanes own a scratch cell of the transpose arrays, a missing task's coefficient rows are
+  // zero and its index run points at the batch array's last slot (never a dof: mfgpu_api.hip); only the adds into
+  // the accumulator are masked for the idle lanes.  No branch in the cell phase.
+  const int lc = lane / n, k = lane - lc * n;  // lc == CW for the idle lanes
+  const bool lane_on = lane < NT;
+  const int tk = lane_on ? lane : NT - 1;  // idle lanes load a valid entry
+
+  // persistent workgroups, XCD-aware contiguous batch ranges (see apply_batches_x)
+  uint32_t b, bstride, bend;
+  {
+    const uint32_t nbt = A.batch_end - A.batch0, G = gridDim.x;
+    if (G >= 8 && nbt >= G) {
+      const uint32_t xcd = blockIdx.x & 7u, slot = blockIdx.x >> 3;
+      const uint32_t q = G >> 3, rem = G & 7u;
+      const uint32_t wlo = xcd * q + (xcd < rem ? xcd : rem);
+      const uint32_t w = q + (xcd < rem ? 1u : 0u);
+      b = A.batch0 + (uint32_t)((uint64_t)nbt * wlo / G) + slot;
+      bend = A.batch0 + (uint32_t)((uint64_t)nbt * (wlo + w) / G);
+      bstride = w;
+    } else {
+      b = A.batch0 + blockIdx.x;
+      bend = A.batch_end;
+      bstride = G;
+    }
+  }
+  if (b >= bend) return;
+  auto next_of = [&](uint32_t x) { return x + bstride < bend ? x + bstride : x; };
+
+  // Per-batch records have FIXED strides (mfgpu_api.hip): every address below is a uniform base (scalar arithmetic
+  // on the batch index) plus a lane offset plus an immediate; nothing is clamped per batch and no load depends on
+  // another batch's metadata.  Vectors and the halo buffer are addressed base + 32-bit byte offset (the plan
+  // guarantees n_dofs < 2^29; shifting a dof-list entry left by 3 also drops its flag bit 31).
+  struct Meta {
+    int nb, nint;
+    uint32_t hoff;
+  };
+  auto meta_of = [&](const uint4 &r) {
+    Meta m;
+    m.nb = __builtin_amdgcn_readfirstlane((int)r.y);
+    m.nint = __builtin_amdgcn_readfirstlane((int)r.z);
+    m.hoff = (uint32_t)__builtin_amdgcn_readfirstlane((int)r.w);
+    return m;
+  };
+  auto load_dofs = [&](uint32_t bb, uint32_t (&g)[KGU]) {
+    const uint32_t *p = A.bdofsp + (size_t)bb * (KGU * 64) + lane;
+#pragma unroll
+    for (int j = 0; j < KGU; ++j) g[j] = nt_load(p + j * 64);
+  };
+  auto src_at = [&](uint32_t g) -> T {
+    return *reinterpret_cast<const T *>(reinterpret_cast<const char *>(A.src) + (uint32_t)(g * (uint32_t)sizeof(T)));
+  };
+  auto dst_at = [&](uint32_t g) -> T * {
+    return reinterpret_cast<T *>(reinterpret_cast<char *>(A.dst) + (uint32_t)(g * (uint32_t)sizeof(T)));
+  };
+  auto load_ix = [&](uint32_t bb, uint32_t (&ix)[NIW]) {
+    const uint32_t *p = A.idxp + (size_t)bb * (NIW * NT) + tk;
+#pragma unroll
+    for (int w = 0; w < NIW; ++w) ix[w] = nt_load(p + w * NT);
+  };
+  // gathered values -> LDS (read_dof_values, fee_gpu.cuh:323-331, once per batch dof).  bdofs bit 31 = constrained
+  // row: reads as 0 (constraint_handler_gpu.cu:258-259).  All KGU * 64 slots are written (the padding of the dof
+  // list repeats its last entry).  The identity rows themselves (dst = src, :286) are written by pass 2 for
+  // EVERY constrained dof (PlanLimits::pass2_owns_constrained): this kernel never stores to a constrained row.
+  auto stage_src = [&](const uint32_t (&g)[KGU], const T (&sv)[KGU]) {
+#pragma unroll
+    for (int j = 0; j < KGU; ++j) {
+      // value & ~(sign of g): bit arithmetic instead of a select, which hipcc turns into a branch per slot
+      const unsigned long long keep = (unsigned long long)(long long)~((int)g[j] >> 31);
+      const double v = (double)sv[j];
+      ua[lane + j * 64] = __longlong_as_double((long long)((unsigned long long)__double_as_longlong(v) & keep));
+    }
+  };
+  // byte offset into ua of entry i = x + n * y of this task's index run (stored pre-multiplied by 8)
+  auto ixb = [&](const uint32_t (&ix)[NIW], int i) -> uint32_t {
+    return (i & 1) ? (ix[i >> 1] >> 16) : (ix[i >> 1] & 0xffffu);
+  };
+  // scatter (distribute_local_to_global, fee_gpu.cuh:346-363), ONE wave-wide store per 64-lane slot and no per-lane
+  // case: the plan (PlanLimits::slot_align) makes the interior dofs of a batch -- its alone, final, never constrained
+  // -- fill whole slots; the slots behind them are partial sums for pass 2 and go to the batch's contiguous, slot-
+  // padded halo region; the slots behind those are padding and go to a sink behind the halo buffer.  The three cases
+  // are wave-uniform: scalar selects of base and offset, no branch (a branch here would let the compiler sink the
+  // contractions of the surrounding steps past the stores).
+  // Per batch three lane values -- (nint - lane), (nb - lane) and the lane's first halo byte offset -- made opaque
+  // to the optimizer; per slot the class falls out of two compares with an immediate.  (Computing the classes from
+  // the scalars nint / nb instead makes hipcc hoist all 17 slots' scalar selects to the top of the iteration and
+  // spill them to VGPR lanes: +140 lane reads / writes per batch.)
+  struct ScatterLane {
+    int d_int, d_all;
+    uint32_t hoff;
+  };
+  auto scatter_lane = [&](const Meta &m) {
+    ScatterLane sl;
+    sl.d_int = m.nint - lane;
+    sl.d_all = m.nb - lane;
+    sl.hoff = (m.hoff - (uint32_t)m.nint + (uint32_t)lane) * (uint32_t)sizeof(T);
+    asm volatile("" : "+v"(sl.d_int), "+v"(sl.d_all), "+v"(sl.hoff));
+    return sl;
+  };
+  const uint32_t sink_off = (A.halo_slots + (uint32_t)lane) * (uint32_t)sizeof(T);
+  auto scatter_slot = [&](int j, const ScatterLane &sl, uint32_t g, T r, T oldv) {
+    int di = sl.d_int, da = sl.d_all;
+    asm volatile("" : "+v"(di), "+v"(da));  // pins the slot's compares and selects HERE (see above)
+    const bool iv = di > 64 * j, nv = da <= 64 * j;  // the same for every lane
+    char *const base = __ballot(iv) != 0 ? reinterpret_cast<char *>(A.dst) : reinterpret_cast<char *>(A.halo);
+    const uint32_t voff = iv ? g * (uint32_t)sizeof(T) : nv ? sink_off : sl.hoff + (uint32_t)(64 * j * (int)sizeof(T));
+    *reinterpret_cast<T *>(base + voff) = (ADD && iv) ? oldv + r : r;
+  };
+
+  uint32_t b1 = next_of(b), b2 = next_of(b1);
+  uint32_t Gp[KGU], Gc[KGU], Gn[KGU], Gnn[KGU];  // dof lists: previous (its scatter is deferred), current, two ahead
+  uint32_t IXc[NIW], IXn[NIW];
+  T Cc[n2];
+  T SVn[KGU], R[KGU], old[KGU];
+  Meta mp = {0, 0, 0u} /* no previous batch yet: every slot of its scatter is padding */, mc = meta_of(A.metap[b]), mn = meta_of(A.metap[b1]);
+  load_dofs(b, Gc);
+  load_dofs(b1, Gn);
+  load_ix(b, IXc);
+  // the idle lanes add into the batch array's last slot, which is never a dof
+  constexpr uint32_t kDummyIx = 8u * (uint32_t)(KGU * 64 - 1) * 0x10001u;
+#pragma unroll
+  for (int w = 0; w < NIW; ++w) IXc[w] = lane_on ? IXc[w] : kDummyIx;
+  {
+    const T *p = A.coefp + (size_t)b * (n2 * NT) + tk;
+#pragma unroll
+    for (int r = 0; r < n2; ++r) Cc[r] = nt_load(p + r * NT);
+  }
+#pragma unroll
+  for (int j = 0; j < KGU; ++j) {
+    SVn[j] = src_at(Gc[j]);
+    Gp[j] = Gc[j];
+    R[j] = T(0);
+    old[j] = T(0);
+  }
+  stage_src(Gc, SVn);
+  WaveSync::sync();
+
+  // LDS bases of this task: xy-plane with z = k (stages A, C) and yz-plane with x = k (stage B)
+  const int pxy = lc * SA + n2 * k;  // + x + n * y
+  const int pyz = lc * SA + k;       // + n * y + n2 * z
+
+  while (true) {
+    const bool has_next = b1 != b;
+    STAMP(0);
+    RSTAMP(8);
+#ifdef MFGPU_STAMPS
+    if (A.stamps && threadIdx.x == 0) A.stamps[(size_t)b * 16 + 10] = blockIdx.x + 1;
+#endif
+    // ---- coalesced loads of the coming batches: metadata and dof list two ahead, index runs one ahead
+    const uint4 mraw = A.metap[b2];
+    load_dofs(b2, Gnn);
+    load_ix(b1, IXn);
+    if (ADD) {
+#pragma unroll
+      for (int j = 0; j < KGU; ++j) old[j] = *dst_at(Gp[j]);
+    }
+    STAMP(1);
+    // The scattered accesses (gather of the next batch's source values, stores of the PREVIOUS batch's results) and
+    // the coefficient rows are spread over the compute steps below, one or two per step: a 64-address gather or
+    // scatter occupies the memory pipeline for ~150 cycles and a lone wave per SIMD has nothing else to hide it with.
+    auto hookA = [&](int s) {  // 2 n steps: the gather of the next batch
+      MFGPU_PIN_VMEM();
+#pragma unroll
+      for (int j = (KGU * s) / (2 * n); j < (KGU * (s + 1)) / (2 * n); ++j) SVn[j] = src_at(Gn[j]);
+      MFGPU_PIN_VMEM();
+    };
+    const ScatterLane slp = scatter_lane(mp);
+    auto hookB = [&](int s) {  // 5 n steps: the previous batch's scatter
+      MFGPU_PIN_VMEM();
+#pragma unroll
+      for (int j = (KGU * s) / (5 * n); j < (KGU * (s + 1)) / (5 * n); ++j) scatter_slot(j, slp, Gp[j], R[j], old[j]);
+      MFGPU_PIN_VMEM();
+    };
+    const T *const cnext = A.coefp + (size_t)b1 * (n2 * NT) + tk;
+    auto hookC = [&](int s) {  // 2 n steps: the next batch's coefficient rows (stage B is done with this batch's)
+      MFGPU_PIN_VMEM();
+#pragma unroll
+      for (int r = (n2 * s) / (2 * n); r < (n2 * (s + 1)) / (2 * n); ++r) Cc[r] = nt_load(cnext + r * NT);
+      MFGPU_PIN_VMEM();
+    };
+
+    // ---- stage A: gather the plane, S_y, then per line S_x and D_x
+    {
+      T u[n2];
+#pragma unroll
+      for (int i = 0; i < n2; ++i)
+        u[i] = (T) * reinterpret_cast<const double *>(reinterpret_cast<const char *>(ua) + ixb(IXc, i));
+#pragma unroll
+      for (int x = 0; x < n; ++x) {
+        T in[n], out[n];
+        get_line<n, 1>(u, x, in);
+        mvt<n, 1>(tab.S, in, out);
+        set_line<n, 1>(u, x, out);
+        hookA(x);
+      }
+#pragma unroll
+      for (int y = 0; y < n; ++y) {
+        T in[n], a[n], bb[n];
+        get_line<n, 0>(u, y, in);
+        mvt<n, 1>(tab.S, in, a);
+        mv<n, -1>(tab.Dt, a, bb);
+#pragma unroll
+        for (int x = 0; x < n; ++x) {
+          Aw[pxy + x + n * y] = a[x];
+          Bw[pxy + x + n * y] = bb[x];
+        }
+        hookA(n + y);
+      }
+    }
+    WaveSync::sync();
+    STAMP(2);
+    // every gather of the batch is done: the array becomes the accumulator
+#pragma unroll
+    for (int j = 0; j < KGU; ++j) ua[lane + j * 64] = 0.0;
+
+    // ---- stage B: plane (y, z) at quadrature index x = k
+    {
+      // x-derivative part: t' = S_z^T (c .* S_z b)
+#pragma unroll
+      for (int y = 0; y < n; ++y) {
+        T in[n], g[n], o[n];
+#pragma unroll
+        for (int z = 0; z < n; ++z) in[z] = Bw[pyz + n * y + n2 * z];
+        mvt<n, 1>(tab.S, in, g);
+#pragma unroll
+        for (int z = 0; z < n; ++z) g[z] *= Cc[y + n * z];
+        mv<n, 1>(tab.S, g, o);
+#pragma unroll
+        for (int z = 0; z < n; ++z) Bw[pyz + n * y + n2 * z] = o[z];
+        hookB(y);
+      }
+      // values at the quadrature points
+      T v[n2], r[n2];
+#pragma unroll
+      for (int y = 0; y < n; ++y) {
+        T in[n], o[n];
+#pragma unroll
+        for (int z = 0; z < n; ++z) in[z] = Aw[pyz + n * y + n2 * z];
+        mvt<n, 1>(tab.S, in, o);
+        set_line<n, 1>(v, y, o);
+        hookB(n + y);
+      }
+      // z-derivative part
+#pragma unroll
+      for (int y = 0; y < n; ++y) {
+        T in[n], g[n], o[n];
+        get_line<n, 1>(v, y, in);
+        mv<n, -1>(tab.Dt, in, g);
+#pragma unroll
+        for (int z = 0; z < n; ++z) g[z] *= Cc[y + n * z];
+        mvt<n, -1>(tab.Dt, g, o);
+        set_line<n, 1>(r, y, o);
+        hookB(2 * n + y);
+      }
+      // y-derivative part
+#pragma unroll
+      for (int z = 0; z < n; ++z) {
+        T in[n], g[n], o[n];
+        get_line<n, 0>(v, z, in);
+        mv<n, -1>(tab.Dt, in, g);
+#pragma unroll
+        for (int y = 0; y < n; ++y) g[y] *= Cc[y + n * z];
+        mvt<n, -1>(tab.Dt, g, o);
+#pragma unroll
+        for (int y = 0; y < n; ++y) r[y + n * z] += o[y];
+        hookB(3 * n + z);
+      }
+      // r' = S_z^T r
+#pragma unroll
+      for (int y = 0; y < n; ++y) {
+        T in[n], o[n];
+        get_line<n, 1>(r, y, in);
+        mv<n, 1>(tab.S, in, o);
+#pragma unroll
+        for (int z = 0; z < n; ++z) Aw[pyz + n * y + n2 * z] = o[z];
+        hookB(4 * n + y);
+      }
+    }
+    WaveSync::sync();
+    STAMP(3);
+
+    // ---- stage C: plane (x, y) at nodal z = k; add into the batch accumulator
+    {
+      T o[n2];
+#pragma unroll
+      for (int y = 0; y < n; ++y) {
+        T rp[n], tp[n], w[n], ol[n];
+#pragma unroll
+        for (int x = 0; x < n; ++x) {
+          rp[x] = Aw[pxy + x + n * y];
+          tp[x] = Bw[pxy + x + n * y];
+        }
+        mvt<n, -1>(tab.Dt, tp, w);
+#pragma unroll
+        for (int x = 0; x < n; ++x) w[x] += rp[x];
+        mv<n, 1>(tab.S, w, ol);
+        set_line<n, 0>(o, y, ol);
+        hookC(y);
+      }
+#pragma unroll
+      for (int x = 0; x < n; ++x) {
+        T in[n], out[n];
+        get_line<n, 1>(o, x, in);
+        mv<n, 1>(tab.S, in, out);
+        set_line<n, 1>(o, x, out);
+        hookC(n + x);
+      }
+#pragma unroll
+      for (int i = 0; i < n2; ++i)
+        lds_add(reinterpret_cast<double *>(reinterpret_cast<char *>(ua) + ixb(IXc, i)), (double)o[i]);
+    }
+    WaveSync::sync();
+    STAMP(4);
+
+    // ---- batch results -> registers (stored during the next iteration); the next batch's gathered values -> LDS:
+    // the iteration's one wait for the gather, issued a stage and a half ago
+#pragma unroll
+    for (int j = 0; j < KGU; ++j) R[j] = (T)ua[lane + j * 64];
+    WaveSync::sync();
+    STAMP(5);
+    stage_src(Gn, SVn);  // (after the last batch: its own values again, unused)
+    STAMP(6);
+    mp = mc;
+#pragma unroll
+    for (int j = 0; j < KGU; ++j) Gp[j] = Gc[j];
+    STAMP(7);
+    RSTAMP(9);
+    if (!has_next) break;
+    WaveSync::sync();
+    b = b1;
+    b1 = b2;
+    b2 = next_of(b2);
+    mc = mn;
+    mn = meta_of(mraw);
+#pragma unroll
+    for (int j = 0; j < KGU; ++j) {
+      Gc[j] = Gn[j];
+      Gn[j] = Gnn[j];
+    }
+#pragma unroll
+    for (int w = 0; w < NIW; ++w) IXc[w] = lane_on ? IXn[w] : kDummyIx;
+  }
+  // the last batch's results
+  if (ADD) {
+#pragma unroll
+    for (int j = 0; j < KGU; ++j) old[j] = *dst_at(Gp[j]);
+  }
+  const ScatterLane sll = scatter_lane(mp);
+#pragma unroll
+  for (int j = 0; j < KGU; ++j) scatter_slot(j, sll, Gp[j], R[j], old[j]);
+}
+
+template <int n, typename T>
+static size_t p_lds_bytes() {
+  return (size_t)p_kgu(n) * 64 * sizeof(double) + (size_t)2 * (p_cells_per_wave(n) + 1) * p_cell_stride(n) * sizeof(T);
+}
+
+template <int n, typename T>
+static hipError_t p_run(const ApplyArgs<T> &a, const double *S, const double *Dt, uint32_t grid, hipStream_t st,
+                        bool configure_only, size_t *lds_out, int *occupancy) {
+  const size_t lds = p_lds_bytes<n, T>();
+  if (lds_out) *lds_out = lds;
+  if (configure_only) {
+    hipError_t e = hipFuncSetAttribute((const void *)apply_planes3<n, T, false>,
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    if (e == hipSuccess)
+      e = hipFuncSetAttribute((const void *)apply_planes3<n, T, true>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                              (int)lds);
+    if (e == hipSuccess && occupancy)
+      e = hipOccupancyMaxActiveBlocksPerMultiprocessor(occupancy, apply_planes3<n, T, false>, 64, lds);
+    return e;
+  }
+  Tables<T, n> tab;
+  for (int i = 0; i < ((n + 1) / 2) * n; ++i) {
+    tab.S[i] = (T)S[i];
+    tab.Dt[i] = (T)Dt[i];
+  }
+  if (a.add)
+    hipLaunchKernelGGL((apply_planes3<n, T, true>), dim3(grid), dim3(64), lds, st, a, tab);
+  else
+    hipLaunchKernelGGL((apply_planes3<n, T, false>), dim3(grid), dim3(64), lds, st, a, tab);
+  return hipGetLastError();
+}
+
+template <typename T>
+hipError_t p_launch(int n, const ApplyArgs<T> &a, const double *S, const double *Dt, uint32_t grid, hipStream_t st,
+                    bool configure_only, size_t *lds_out, int *occupancy) {
+  switch (n) {
+    case 3: return p_run<3, T>(a, S, Dt, grid, st, configure_only, lds_out, occupancy);
+    case 4: return p_run<4, T>(a, S, Dt, grid, st, configure_only, lds_out, occupancy);
+    case 5: return p_run<5, T>(a, S, Dt, grid, st, configure_only, lds_out, occupancy);
+    default: return hipErrorInvalidValue;
+  }
+}
+
+template hipError_t p_launch<double>(int, const ApplyArgs<double> &, const double *, const double *, uint32_t,
+                                     hipStream_t, bool, size_t *, int *);
+template hipError_t p_launch<float>(int, const ApplyArgs<float> &, const double *, const double *, uint32_t,
+                                    hipStream_t, bool, size_t *, int *);
+
+// coefficient in plan cell order [cell][q] -> per batch [row r = y + n z][NT tasks = cell_in_batch * n + x]
+// (fixed record size n*n*NT per batch; the tasks of a ragged batch's missing cells stay zero)
+template <typename T>
+__global__ void relayout_coef_kernel(T *out, const T *in, const uint32_t *cell_batch, const uint32_t *cell_pos,
+                                     size_t total, int n) {
+  const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= total) return;
+  const int n2 = n * n, nd = n2 * n, NT = (64 / n) * n;
+  const size_t cell = i / nd;
+  const int q = (int)(i - cell * nd);
+  const int x = q % n, r = q / n;  // r = y + n z
+  out[((size_t)cell_batch[cell] * n2 + r) * NT + cell_pos[cell] * n + x] = in[i];
+}
+
+template <typename T>
+hipError_t relayout_coef_launch(T *out, const T *in, const uint32_t *cell_batch, const uint32_t *cell_pos,
+                                size_t total, int n, hipStream_t st) {
+  if (total == 0) return hipSuccess;
+  hipLaunchKernelGGL(relayout_coef_kernel<T>, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, out, in,
+                     cell_batch, cell_pos, total, n);
+  return hipGetLastError();
+}
+template hipError_t relayout_coef_launch<double>(double *, const double *, const uint32_t *, const uint32_t *, size_t,
+                                                 int, hipStream_t);
+template hipError_t relayout_coef_launch<float>(float *, const float *, const uint32_t *, const uint32_t *, size_t, int,
+                                                hipStream_t);
+
+}  // namespace mfgpu

@@ -90,7 +90,7 @@ static void default_batch_limits(const mfgpu_desc &d, uint32_t max_chunks, uint3
   if (max_cells < 1) max_cells = 1;
 }
 
-int build_plan(const mfgpu_desc &d, Plan &P, uint32_t max_chunks) {
+int build_plan(const mfgpu_desc &d, Plan &P, uint32_t max_chunks, const PlanLimits *limits) {
   if (d.dim != 2 && d.dim != 3) {
     set_error("dim must be 2 or 3");
     return MFGPU_EINVAL;
@@ -135,7 +135,17 @@ int build_plan(const mfgpu_desc &d, Plan &P, uint32_t max_chunks) {
     return MFGPU_EUNSUPPORTED;
   }
   uint32_t Bmax, NBmax;
-  default_batch_limits(d, max_chunks, Bmax, NBmax);
+  if (limits && limits->max_cells && limits->max_dofs) {
+    // kernel-imposed limits; the caller's knobs may only tighten them
+    Bmax = d.max_cells_per_batch ? std::min(d.max_cells_per_batch, limits->max_cells) : limits->max_cells;
+    NBmax = d.max_dofs_per_batch ? std::min(d.max_dofs_per_batch, limits->max_dofs) : limits->max_dofs;
+    if (NBmax < (uint32_t)P.nd) {
+      set_error("max_dofs_per_batch is smaller than one cell");
+      return MFGPU_EINVAL;
+    }
+  } else {
+    default_batch_limits(d, max_chunks, Bmax, NBmax);
+  }
 
   // dof -> cells incidence (CSR)
   std::vector<uint32_t> dc_off(N + 1, 0);
@@ -146,6 +156,17 @@ int build_plan(const mfgpu_desc &d, Plan &P, uint32_t max_chunks) {
     std::vector<uint32_t> pos(dc_off.begin(), dc_off.end() - 1);
     for (uint32_t c = 0; c < nc; ++c)
       for (uint32_t i = 0; i < nd; ++i) dc[pos[l2g[(uint64_t)c * nd + i]]++] = c;
+    // a cell that lists one dof twice (substituted / degenerate loc2glob) counts once: the cells of a dof are
+    // in ascending order, so duplicates are adjacent
+    uint32_t w = 0;
+    for (uint32_t g = 0; g < N; ++g) {
+      const uint32_t beg = dc_off[g], end = dc_off[g + 1];
+      dc_off[g] = w;
+      for (uint32_t k = beg; k < end; ++k)
+        if (k == beg || dc[k] != dc[k - 1]) dc[w++] = dc[k];
+    }
+    dc_off[N] = w;
+    dc.resize(w);
   }
 
   // ---- greedy batching: grow from the lowest unassigned cell, always adding the candidate that
@@ -224,18 +245,33 @@ int build_plan(const mfgpu_desc &d, Plan &P, uint32_t max_chunks) {
       for (uint32_t i = 0; i < nd; ++i) v.push_back(l2g[(uint64_t)c * nd + i]);
     std::sort(v.begin(), v.end());
     v.erase(std::unique(v.begin(), v.end()), v.end());
-    if (v.size() > 65535u) {
-      set_error("internal: batch exceeds 65535 dofs");
+    if (v.size() > NBmax || v.size() > 8191u) {
+      // (the greedy estimate nd - gain under-counts a cell that lists one dof twice; the kernels hold a batch's
+      // dofs in a fixed number of register / LDS slots and byte offsets of batch-local ids in 16 bits)
+      set_error("internal: batch exceeds the kernel's dof slots (degenerate loc2glob?)");
       return MFGPU_EINVAL;
     }
     for (uint32_t g : v) ntouch[g]++;
   }
+  // A dof takes the pass-2 route ("shared") if two or more batches touch it.  With limits->slot_align (apply_planes3:
+  // 64, one wave-wide store per slot, no per-lane case distinction) two more kinds are DEMOTED to that route although
+  // only this batch touches them (one partial sum; pass 2 copies it): constrained dofs -- pass 2 writes the identity
+  // row of every constrained dof it lists, so the cell loop never stores to one -- and the last (count mod slot_align)
+  // interior dofs, so that the interior part of every batch fills whole slots.
+  const uint32_t slot_align = limits ? limits->slot_align : 0u;
+  std::vector<uint8_t> shared_flag(N, 0);
+  for (uint32_t g = 0; g < N; ++g) shared_flag[g] = ntouch[g] >= 2 || (slot_align && ntouch[g] == 1 && constrained[g]);
   std::vector<uint32_t> nint(nb, 0);
   for (uint32_t b = 0; b < nb; ++b) {
     std::vector<uint32_t> &v = bd[b];
-    std::stable_partition(v.begin(), v.end(), [&](uint32_t g) { return ntouch[g] == 1; });
+    std::stable_partition(v.begin(), v.end(), [&](uint32_t g) { return !shared_flag[g]; });
     uint32_t k = 0;
-    while (k < v.size() && ntouch[v[k]] == 1) ++k;
+    while (k < v.size() && !shared_flag[v[k]]) ++k;
+    if (slot_align) {
+      const uint32_t keep = k - k % slot_align;
+      for (uint32_t t = keep; t < k; ++t) shared_flag[v[t]] = 1;
+      k = keep;
+    }
     nint[b] = k;
   }
 
@@ -284,7 +320,7 @@ int build_plan(const mfgpu_desc &d, Plan &P, uint32_t max_chunks) {
   for (uint32_t k = 0; k < nb; ++k) rank_of[order[k]] = k;
   std::vector<uint32_t> shared_ids;
   for (uint32_t g = 0; g < N; ++g)
-    if (ntouch[g] >= 2) shared_ids.push_back(g);
+    if (shared_flag[g]) shared_ids.push_back(g);
   const size_t ns = shared_ids.size();
   std::vector<uint32_t> sid(N, NONE), t_off(ns + 1, 0);
   for (size_t i = 0; i < ns; ++i) {
@@ -335,7 +371,12 @@ int build_plan(const mfgpu_desc &d, Plan &P, uint32_t max_chunks) {
     const uint32_t b = order[k];
     const std::vector<uint32_t> &v = bd[b];
     P.batch_nint.push_back(nint[b]);
-    P.halo_off.push_back(P.halo_off.back() + (uint32_t)(v.size() - nint[b]));
+    {
+      // (slot_align: the kernel stores whole slots, so a batch's halo region is padded to whole slots too)
+      uint32_t nsh = (uint32_t)(v.size() - nint[b]);
+      if (slot_align) nsh = (nsh + slot_align - 1) / slot_align * slot_align;
+      P.halo_off.push_back(P.halo_off.back() + nsh);
+    }
     for (uint32_t g : v) {
       uint8_t f = 0;
       if (constrained[g]) f |= kFlagConstrained;

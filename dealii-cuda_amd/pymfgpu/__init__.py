@@ -17,6 +17,7 @@ LIB_PATH = os.environ.get("MFGPU_LIB") or os.path.join(os.path.dirname(_HERE), "
 
 F64, F32 = 0, 1
 UNIFORM_J0, HANGING_NODES, COLORED_SCATTER = 1, 2, 1 << 8
+KERNEL_AUTO, KERNEL_PENCILS, KERNEL_PENCILS_X, KERNEL_PLANES = 0, 1, 2, 3  # Desc.kernel
 
 
 class MfgpuError(RuntimeError):
@@ -33,6 +34,7 @@ class Desc(C.Structure):
         ("quadrature_points", C.c_void_p), ("shape_values", C.c_void_p), ("shape_gradients", C.c_void_p),
         ("constraint_weights", C.c_void_p), ("constrained_dofs", C.c_void_p),
         ("n_constrained", C.c_uint32), ("max_cells_per_batch", C.c_uint32), ("max_dofs_per_batch", C.c_uint32),
+        ("kernel", C.c_uint32),
     ]
 
 
@@ -220,7 +222,7 @@ class Mesh:
 def make_desc(dim, degree, n_dofs, loc2glob, JxW, inv_jac, coefficient, constrained,
               shape_values, shape_gradients, number_type=F64, constraint_mask=None,
               constraint_weights=None, quadrature_points=None, max_cells_per_batch=0, max_dofs_per_batch=0,
-              colored=False):
+              colored=False, kernel=0):
     """Build a Desc from numpy arrays; returns (desc, keepalive list)."""
     dt = np_dtype(number_type)
     keep = []
@@ -256,6 +258,7 @@ def make_desc(dim, degree, n_dofs, loc2glob, JxW, inv_jac, coefficient, constrai
     d.n_constrained = c.size
     d.max_cells_per_batch = max_cells_per_batch
     d.max_dofs_per_batch = max_dofs_per_batch
+    d.kernel = kernel
     return d, keep
 
 

@@ -90,7 +90,14 @@ typedef struct mfgpu_desc {
      cells_per_block_shmem, matrix_free_gpu.h:298-315) */
   uint32_t max_cells_per_batch;
   uint32_t max_dofs_per_batch;
+  uint32_t kernel; /* MFGPU_KERNEL_*: which cell-loop kernel family to use; 0 = the library's choice */
 } mfgpu_desc;
+
+/* mfgpu_desc.kernel (all variants compute the same operator; non-default ones exist for tests and measurements) */
+#define MFGPU_KERNEL_AUTO 0
+#define MFGPU_KERNEL_PENCILS 1   /* apply_batches: a thread owns a 1D pencil, 2 workgroups per CU (2D; coloured mode)   */
+#define MFGPU_KERNEL_PENCILS_X 2 /* apply_batches_x: the same for 3 workgroups per CU (3D two-pass; hanging nodes)      */
+#define MFGPU_KERNEL_PLANES 3    /* apply_planes3: a thread owns a 2D plane, one wave per batch (3D conforming, p = 2..4) */
 
 /* ---- operator (replaces LaplaceOperatorGpu::reinit / vmult / vmult_add / clear) -------- */
 

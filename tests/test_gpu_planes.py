@@ -1,0 +1,93 @@
+"""GPU parity tests of the plane-per-thread cell loop (apply_planes3, mfgpu_kernels_p.hip) against the oracle, through
+the C-ABI: batch sizes from one cell to a full wave (64 / n cells), ragged last batches, every supported degree, both
+number types, vmult and vmult_add, Dirichlet rows owned by one batch and shared by several, and the kernel families
+it replaced on the same inputs (mfgpu_desc.kernel).
+
+Tolerance: relative l2 <= 1e-12 in double, <= 1e-5 in float (north_star / BASELINE.md section 2)."""
+import numpy as np
+import pytest
+
+import pymfgpu as mf
+from oracle import mf_oracle as o
+from test_gpu import TOL, gpu_vmult, rel
+from util import desc_from_oracle, oracle_desc_from_mesh
+
+pytestmark = pytest.mark.gpu
+
+# (p, cells per direction): meshes with several batches of the default size (64 / n cells), ragged remainders included
+SIZES = [(2, 5), (2, 9), (3, 4), (3, 7), (4, 3), (4, 5), (4, 7)]
+
+
+@pytest.mark.parametrize("p,n", SIZES)
+@pytest.mark.parametrize("nt", [mf.F64, mf.F32])
+def test_planes_vmult_and_add(p, n, nt):
+    mesh = mf.Mesh.uniform(3, p, n, number_type=nt)
+    od = oracle_desc_from_mesh(mesh, dtype=np.float64)
+    mesh.desc.kernel = mf.KERNEL_PLANES
+    op = mf.Operator(mesh.desc, mesh)
+    assert op.kernel_name() == "apply_planes3"
+    st = op.plan_stats()
+    assert st["max_batch_cells"] <= 64 // (p + 1) and st["n_batches"] >= 2
+    rng = np.random.default_rng(1000 * p + n)
+    x, y0 = rng.standard_normal(mesh.n_dofs), rng.standard_normal(mesh.n_dofs)
+    xt = x.astype(mf.np_dtype(nt)).astype(np.float64)
+    assert rel(gpu_vmult(op, x, nt), o.vmult(od, xt)) <= TOL[nt]
+    y0t = y0.astype(mf.np_dtype(nt)).astype(np.float64)
+    assert rel(gpu_vmult(op, x, nt, y0=y0), o.vmult_add(od, y0t, xt)) <= TOL[nt]
+
+
+@pytest.mark.parametrize("p,n,cells", [(4, 4, 1), (4, 4, 2), (4, 4, 5), (4, 5, 7), (4, 6, 12), (3, 5, 3), (3, 6, 16),
+                                       (2, 7, 4), (2, 8, 21)])
+def test_planes_batch_sizes(p, n, cells):
+    """batches of 1 .. 64/n cells (partly filled waves, idle lanes) give the same operator"""
+    od = o.uniform_mesh_desc(3, p, n, coefficient=lambda x: 1.0 + x[..., 0] ** 2 + 0.5 * np.sin(3 * x[..., 1]) + x[..., 2])
+    x = np.random.default_rng(p * 100 + n * 10 + cells).standard_normal(od.n_dofs)
+    desc, keep = desc_from_oracle(od, max_cells_per_batch=cells, kernel=mf.KERNEL_PLANES)
+    op = mf.Operator(desc, keep)
+    assert op.kernel_name() == "apply_planes3"
+    assert op.plan_stats()["max_batch_cells"] <= cells
+    assert rel(gpu_vmult(op, x), o.vmult(od, x)) <= 1e-12
+
+
+def test_planes_agree_with_the_pencil_kernels():
+    """same mesh, same vector through the three kernel families: each within 1e-12 of the oracle, and of each other"""
+    mesh = mf.Mesh.uniform(3, 4, 6)
+    od = oracle_desc_from_mesh(mesh)
+    x = np.random.default_rng(5).standard_normal(mesh.n_dofs)
+    ref = o.vmult(od, x)
+    out = {}
+    for kern, name in ((mf.KERNEL_PLANES, "apply_planes3"), (mf.KERNEL_PENCILS_X, "apply_batches_x"),
+                       (mf.KERNEL_PENCILS, "apply_batches")):
+        mesh.desc.kernel = kern
+        op = mf.Operator(mesh.desc, mesh)
+        assert op.kernel_name() == name
+        out[name] = gpu_vmult(op, x)
+        assert rel(out[name], ref) <= 1e-12
+    assert rel(out["apply_planes3"], out["apply_batches_x"]) <= 1e-12
+
+
+def test_planes_chained_applies_and_determinism():
+    """bmop protocol (bmop.cu:134-146): dst = 0.1; repeat {swap; vmult}; bit-identical when repeated"""
+    mesh = mf.Mesh.uniform(3, 4, 4)
+    od = oracle_desc_from_mesh(mesh)
+    op = mf.Operator(mesh.desc, mesh)
+    assert op.kernel_name() == "apply_planes3"
+    runs = []
+    for _ in range(2):
+        a, b = mf.DeviceVector(mesh.n_dofs), mf.DeviceVector(mesh.n_dofs)
+        b.fill(0.1)
+        for _ in range(3):
+            a, b = b, a
+            op.vmult(b, a)
+        mf.synchronize()
+        runs.append(b.to_host())
+    np.testing.assert_array_equal(runs[0], runs[1])
+    ref = o.bmop_protocol(od, 3)
+    assert rel(runs[0], ref) <= 1e-12 * 100 ** 2
+
+
+def test_planes_unsupported_requests_fail_loudly():
+    mesh = mf.Mesh.uniform(2, 2, 4)
+    mesh.desc.kernel = mf.KERNEL_PLANES
+    with pytest.raises(mf.MfgpuError):
+        mf.Operator(mesh.desc, mesh)
