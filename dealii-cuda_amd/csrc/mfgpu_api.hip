@@ -44,9 +44,9 @@ struct mfgpu_handle {
   void *d_tab2 = nullptr;  // [2][n*n] squared 1D tables of the diagonal kernel, built on first use
   // two-pass mode
   bool twopass = true;
-  uint32_t *d_batch_nint = nullptr, *d_halo_off = nullptr, *d_sdofs = nullptr, *d_s_off = nullptr,
-           *d_s_idx = nullptr, *d_chunks = nullptr, *d_gstarts = nullptr;
-  bool grouped = false;  // pass 2 by toucher groups (reduce_groups) instead of the per-dof CSR (reduce_shared)
+  uint32_t *d_batch_nint = nullptr, *d_halo_off = nullptr;
+  uint32_t *d_p2arr = nullptr, *d_p2tiles = nullptr;  // pass 2, class-sorted form (mfgpu_pass2.hip)
+  uint32_t n_p2tiles = 0;
   void *d_halo = nullptr;
   unsigned long long *d_stamps = nullptr;  // diagnostic build only
   size_t lds = 0, device_bytes = 0;
@@ -194,18 +194,12 @@ int create_typed(mfgpu_handle *h, const mfgpu_desc &d) {
   if (h->twopass) {
     if ((rc = dev_upload(&h->d_batch_nint, P.batch_nint.data(), P.batch_nint.size() * 4, acct))) return rc;
     if ((rc = dev_upload(&h->d_halo_off, P.halo_off.data(), P.halo_off.size() * 4, acct))) return rc;
-    if ((rc = dev_upload(&h->d_sdofs, P.sdofs.data(), P.sdofs.size() * 4, acct))) return rc;
-    // grouped pass 2 on conforming meshes when a chunk (<= 64 dofs of one toucher group, one wave) holds 16
-    // dofs or more on average (faces of 121 dofs at p=4): 32 vs 33 us on C2 and 28 MB less index data.
-    // Meshes with hanging nodes have many tiny groups (C3: 0.51 vs 0.47 ms per vmult) and keep the CSR.
-    h->grouped = !h->hn && !P.chunks.empty() && (P.chunks.size() / 4) * 16 <= P.sdofs.size();
-    if (const char *e = getenv("MFGPU_GROUPS")) h->grouped = atoi(e) != 0 && !P.chunks.empty();
-    if (h->grouped) {
-      if ((rc = dev_upload(&h->d_chunks, P.chunks.data(), P.chunks.size() * 4, acct))) return rc;
-      if ((rc = dev_upload(&h->d_gstarts, P.gstarts.data(), P.gstarts.size() * 4, acct))) return rc;
-    } else {
-      if ((rc = dev_upload(&h->d_s_off, P.s_off.data(), P.s_off.size() * 4, acct))) return rc;
-      if ((rc = dev_upload(&h->d_s_idx, P.s_idx.data(), P.s_idx.size() * 4, acct))) return rc;
+    {
+      std::vector<uint32_t> arr, tiles;
+      build_pass2_classes(P.sdofs, P.s_off, P.s_idx, arr, tiles);
+      h->n_p2tiles = (uint32_t)(tiles.size() / 4);
+      if ((rc = dev_upload(&h->d_p2arr, arr.data(), arr.size() * 4, acct))) return rc;
+      if ((rc = dev_upload(&h->d_p2tiles, tiles.data(), tiles.size() * 4, acct))) return rc;
     }
     if (h->pk && P.halo_off.back() + 64ull >= (1ull << 29)) {
       set_error("halo buffer too large for 32-bit byte offsets");
@@ -467,12 +461,9 @@ int vmult_typed(mfgpu_handle *h, void *dst, const void *src, hipStream_t st, int
       h->ev_used += 2;
     }
   }
-  if (h->twopass && h->grouped)
-    HIP_TRY(reduce_groups_launch<T>((T *)dst, (const T *)src, (const T *)h->d_halo, h->d_sdofs, h->d_chunks,
-                                    h->d_gstarts, (uint32_t)(P.chunks.size() / 4), add, st));
-  else if (h->twopass)
-    HIP_TRY(reduce_launch<T>((T *)dst, (const T *)src, (const T *)h->d_halo, h->d_sdofs, h->d_s_off, h->d_s_idx,
-                             (uint32_t)P.sdofs.size(), add, st));
+  if (h->twopass)
+    HIP_TRY(reduce_classes_launch<T>((T *)dst, (const T *)src, (const T *)h->d_halo, h->d_p2arr, h->d_p2tiles,
+                                     h->n_p2tiles, add, st));
   HIP_TRY(orphan_launch<T>((T *)dst, (const T *)src, h->d_orphans, (uint32_t)P.orphans.size(), add, st));
   if (h->prof) h->prof_vmults++;
   return 0;
@@ -672,11 +663,8 @@ void mfgpu_destroy(mfgpu_handle *h) {
   hipFree(h->d_hnw);
   hipFree(h->d_batch_nint);
   hipFree(h->d_halo_off);
-  hipFree(h->d_sdofs);
-  hipFree(h->d_s_off);
-  hipFree(h->d_s_idx);
-  hipFree(h->d_chunks);
-  hipFree(h->d_gstarts);
+  hipFree(h->d_p2arr);
+  hipFree(h->d_p2tiles);
   hipFree(h->d_halo);
   hipFree(h->d_stamps);
   for (hipEvent_t e : h->ev) hipEventDestroy(e);

@@ -56,6 +56,12 @@ hipError_t apply_launch(int dim, int n, const ApplyArgs<T> &a, const double *S, 
                         bool hn, bool twopass, bool wave, uint32_t grid, hipStream_t st);
 template <typename T>
 hipError_t apply_occupancy(int dim, int n, bool hn, bool twopass, bool wave, size_t lds, int *blocks);
+// pass 2, class-sorted structure-of-arrays form (mfgpu_pass2.hip)
+void build_pass2_classes(const std::vector<uint32_t> &sdofs, const std::vector<uint32_t> &s_off,
+                         const std::vector<uint32_t> &s_idx, std::vector<uint32_t> &arr, std::vector<uint32_t> &tiles);
+template <typename T>
+hipError_t reduce_classes_launch(T *dst, const T *src, const T *halo, const uint32_t *arr, const uint32_t *tiles,
+                                 uint32_t n_tiles, int add, hipStream_t st);
 template <typename T>
 hipError_t reduce_launch(T *dst, const T *src, const T *halo, const uint32_t *sdofs, const uint32_t *s_off,
                          const uint32_t *s_idx, uint32_t ns, int add, hipStream_t st);

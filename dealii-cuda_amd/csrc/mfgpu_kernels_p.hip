@@ -285,14 +285,20 @@ apply_planes3(const ApplyArgs<T> A, const Tables<T, n> tab) {
 #pragma unroll
     for (int j = 0; j < KGU; ++j) ua[lane + j * 64] = 0.0;
 
-    // ---- stage B: plane (y, z) at quadrature index x = k
+    // ---- stage B: plane (y, z) at quadrature index x = k.  The LDS reads of a line are issued one step ahead of
+    // its contractions (a lone wave per SIMD has nothing else to cover the LDS latency with).
     {
+      T nx[n];  // the next line to be processed, in flight
+#pragma unroll
+      for (int z = 0; z < n; ++z) nx[z] = Bw[pyz + n2 * z];
       // x-derivative part: t' = S_z^T (c .* S_z b)
 #pragma unroll
       for (int y = 0; y < n; ++y) {
         T in[n], g[n], o[n];
 #pragma unroll
-        for (int z = 0; z < n; ++z) in[z] = Bw[pyz + n * y + n2 * z];
+        for (int z = 0; z < n; ++z) in[z] = nx[z];
+#pragma unroll
+        for (int z = 0; z < n; ++z) nx[z] = y + 1 < n ? Bw[pyz + n * (y + 1) + n2 * z] : Aw[pyz + n2 * z];
         mvt<n, 1>(tab.S, in, g);
 #pragma unroll
         for (int z = 0; z < n; ++z) g[z] *= Cc[y + n * z];
@@ -307,7 +313,11 @@ apply_planes3(const ApplyArgs<T> A, const Tables<T, n> tab) {
       for (int y = 0; y < n; ++y) {
         T in[n], o[n];
 #pragma unroll
-        for (int z = 0; z < n; ++z) in[z] = Aw[pyz + n * y + n2 * z];
+        for (int z = 0; z < n; ++z) in[z] = nx[z];
+        if (y + 1 < n) {
+#pragma unroll
+          for (int z = 0; z < n; ++z) nx[z] = Aw[pyz + n * (y + 1) + n2 * z];
+        }
         mvt<n, 1>(tab.S, in, o);
         set_line<n, 1>(v, y, o);
         hookB(n + y);
@@ -354,13 +364,26 @@ apply_planes3(const ApplyArgs<T> A, const Tables<T, n> tab) {
     // ---- stage C: plane (x, y) at nodal z = k; add into the batch accumulator
     {
       T o[n2];
+      T nr[n], nt[n];  // the next line, in flight
+#pragma unroll
+      for (int x = 0; x < n; ++x) {
+        nr[x] = Aw[pxy + x];
+        nt[x] = Bw[pxy + x];
+      }
 #pragma unroll
       for (int y = 0; y < n; ++y) {
         T rp[n], tp[n], w[n], ol[n];
 #pragma unroll
         for (int x = 0; x < n; ++x) {
-          rp[x] = Aw[pxy + x + n * y];
-          tp[x] = Bw[pxy + x + n * y];
+          rp[x] = nr[x];
+          tp[x] = nt[x];
+        }
+        if (y + 1 < n) {
+#pragma unroll
+          for (int x = 0; x < n; ++x) {
+            nr[x] = Aw[pxy + x + n * (y + 1)];
+            nt[x] = Bw[pxy + x + n * (y + 1)];
+          }
         }
         mvt<n, -1>(tab.Dt, tp, w);
 #pragma unroll
