@@ -33,7 +33,6 @@ struct mfgpu_handle {
   uint16_t *d_lmapx = nullptr;
   uint16_t *d_perm = nullptr;  // apply_batches_x: bank-conflict-free lane -> pencil maps of the y- and z-stage
   // apply_planes3: fixed-size per-batch records (see ApplyArgs)
-  uint4 *d_metap = nullptr;
   uint32_t *d_bdofsp = nullptr, *d_idxp = nullptr;
   void *d_coefp = nullptr;
   void *d_coef = nullptr;
@@ -157,36 +156,41 @@ int create_typed(mfgpu_handle *h, const mfgpu_desc &d) {
     if ((rc = dev_upload(&h->d_lmapx, lx.data(), lx.size() * 2, acct))) return rc;
   }
   if (h->pk) {
-    // Fixed-size per-batch records of apply_planes3: metadata, the dof list padded to p_kgu * 64 entries with its
-    // last entry, and per task (cell c, plane k) the n*n batch-local ids of the xy-plane z = k as byte offsets
-    // (id * 8) packed two per word, stored [word][task] so that a wave reads consecutive words.
-    const int n = P.n, n2 = n * n, NT = p_cells_per_wave(n) * n, NIW = (n2 + 1) / 2, NB = p_kgu(n) * 64;
+    // Fixed-size per-batch records of apply_planes3.  Dof list: p_ji slots of interior dofs, padded with a pass-2 dof
+    // of the batch (the padding lanes store the zero their never-touched accumulator slot holds, or old + 0, to a dof
+    // pass 2 rewrites), then p_hs slots of pass-2 dofs, padded with the last one.  Index runs: per task (cell c, plane
+    // k) the n*n slot numbers of the xy-plane z = k as byte offsets (slot * 8) packed two per word, stored
+    // [word][task] so that a wave reads consecutive words; the tasks of cells a ragged batch does not have point at
+    // the list's last slot, which is padding in every batch the planner accepts.
+    const int n = P.n, n2 = n * n, NT = p_cells_per_wave(n) * n, NIW = (n2 + 1) / 2;
+    const int JI = p_ji(n) * 64, NB = p_kgu(n) * 64;
     const size_t nbat = P.batch_cell_off.size() - 1;
-    // (the tasks of cells a ragged batch does not have point at the batch array's last slot, which is never a dof:
-    // the planner keeps every batch below NB dofs)
     const uint32_t dummy = 8u * (uint32_t)(NB - 1);
-    std::vector<uint32_t> meta(4 * nbat), bd((size_t)NB * nbat), ix((size_t)NIW * NT * nbat, dummy | (dummy << 16));
+    std::vector<uint32_t> bd((size_t)NB * nbat), ix((size_t)NIW * NT * nbat, dummy | (dummy << 16));
+    std::vector<uint32_t> slot_of;  // batch-local id (position in P.bdofs) -> slot
     for (size_t b = 0; b < nbat; ++b) {
       const uint32_t c0 = P.batch_cell_off[b], nc = P.batch_cell_off[b + 1] - c0;
-      const uint32_t d0 = P.batch_dof_off[b], nbd = P.batch_dof_off[b + 1] - d0;
-      if ((int)nc * n > NT || (int)nbd >= NB) {
-        set_error("internal: batch exceeds the plane kernel's slots");
+      const uint32_t d0 = P.batch_dof_off[b], nbd = P.batch_dof_off[b + 1] - d0, ni = P.batch_nint[b];
+      if ((int)nc * n > NT || (int)ni > JI || (int)(nbd - ni) >= NB - JI || nbd == ni) {
+        set_error("internal: batch does not fit the plane kernel's dof-list slots");
         return MFGPU_EINVAL;
       }
-      meta[4 * b + 0] = nc;
-      meta[4 * b + 1] = nbd;
-      meta[4 * b + 2] = P.batch_nint[b];
-      meta[4 * b + 3] = P.halo_off[b];
-      for (int t = 0; t < NB; ++t) bd[b * NB + t] = P.bdofs[d0 + ((uint32_t)t < nbd ? (uint32_t)t : nbd - 1)];
+      slot_of.assign(nbd, 0u);
+      for (uint32_t t = 0; t < nbd; ++t) slot_of[t] = t < ni ? t : (uint32_t)JI + (t - ni);
+      for (int t = 0; t < NB; ++t) {
+        uint32_t src_t;
+        if (t < JI) src_t = (uint32_t)t < ni ? (uint32_t)t : ni;  // padding: the first pass-2 dof
+        else src_t = std::min<uint32_t>(ni + (uint32_t)(t - JI), nbd - 1);
+        bd[b * NB + t] = P.bdofs[d0 + src_t];
+      }
       for (uint32_t c = 0; c < nc; ++c)
         for (int k = 0; k < n; ++k)
           for (int i = 0; i < n2; ++i) {
-            const uint32_t off = 8u * P.lmap[(size_t)(c0 + c) * P.nd + i + n2 * k];
+            const uint32_t off = 8u * slot_of[P.lmap[(size_t)(c0 + c) * P.nd + i + n2 * k]];
             uint32_t &w = ix[(b * NIW + i / 2) * NT + c * n + k];
             w = (i & 1) ? ((w & 0xffffu) | (off << 16)) : ((w & 0xffff0000u) | off);
           }
     }
-    if ((rc = dev_upload(&h->d_metap, meta.data(), meta.size() * 4, acct))) return rc;
     if ((rc = dev_upload(&h->d_bdofsp, bd.data(), bd.size() * 4, acct))) return rc;
     if ((rc = dev_upload(&h->d_idxp, ix.data(), ix.size() * 4, acct))) return rc;
   }
@@ -201,11 +205,11 @@ int create_typed(mfgpu_handle *h, const mfgpu_desc &d) {
       if ((rc = dev_upload(&h->d_p2arr, arr.data(), arr.size() * 4, acct))) return rc;
       if ((rc = dev_upload(&h->d_p2tiles, tiles.data(), tiles.size() * 4, acct))) return rc;
     }
-    if (h->pk && P.halo_off.back() + 64ull >= (1ull << 29)) {
+    if (h->pk && (uint64_t)P.halo_off.back() >= (1ull << 29)) {
       set_error("halo buffer too large for 32-bit byte offsets");
       return MFGPU_EUNSUPPORTED;
     }
-    const size_t hb = ((size_t)P.halo_off.back() + (h->pk ? 64 : 0)) * sizeof(T);  // + apply_planes3's store sink
+    const size_t hb = (size_t)P.halo_off.back() * sizeof(T);
     if (hb) {
       HIP_TRY(hipMalloc(&h->d_halo, hb));
       HIP_TRY(hipMemset(h->d_halo, 0, hb));
@@ -399,11 +403,9 @@ int vmult_typed(mfgpu_handle *h, void *dst, const void *src, hipStream_t st, int
   a.lmap = h->d_lmap;
   a.lmapx = h->d_lmapx;
   a.perm = h->d_perm;
-  a.metap = h->d_metap;
   a.bdofsp = h->d_bdofsp;
   a.idxp = h->d_idxp;
   a.coefp = (const T *)h->d_coefp;
-  a.halo_slots = P.halo_off.back();
   a.coef = (const T *)h->d_coef;
   a.cmask = h->d_cmask;
   a.hn_weights = (const T *)h->d_hnw;
@@ -604,8 +606,10 @@ int mfgpu_create(const mfgpu_desc *desc, mfgpu_handle **out) {
   if (h->pk) {
     h->xk = false;
     lim.max_cells = (uint32_t)p_cells_per_wave(d.degree + 1);
-    lim.max_dofs = (uint32_t)p_kgu(d.degree + 1) * 64u - 1u;  // the batch array's last slot stays free (idle tasks)
-    lim.slot_align = 64;
+    lim.max_dofs = (uint32_t)p_kgu(d.degree + 1) * 64u - 1u;
+    lim.interior_max = (uint32_t)p_ji(d.degree + 1) * 64u;
+    lim.halo_stride = (uint32_t)p_hs(d.degree + 1) * 64u;
+    lim.shared_max = lim.halo_stride - 1u;  // the list's last slot stays padding (idle tasks)
   }
   // apply_batches_x unrolls 4 chunks at p=3 (64-cell batches = 13^3 dofs like p=4); everything else 3
   int rc = build_plan(dplan, h->plan, (h->xk && d.degree == 3) ? 4u : 3u, h->pk ? &lim : nullptr);
@@ -651,7 +655,6 @@ void mfgpu_destroy(mfgpu_handle *h) {
   hipFree(h->d_lmap);
   hipFree(h->d_lmapx);
   hipFree(h->d_perm);
-  hipFree(h->d_metap);
   hipFree(h->d_bdofsp);
   hipFree(h->d_idxp);
   hipFree(h->d_coefp);

@@ -18,11 +18,16 @@ inline int ipow(int a, int e) {
   return r;
 }
 
-// ---- apply_planes3 (mfgpu_kernels_p.hip): a wave owns 64 / n cells (n lanes per cell); a batch's dof list passes
-// through p_kgu(n) 64-lane register slots; cells of the LDS transpose arrays are p_cell_stride(n) values apart
-// (stride = n mod 32: the 16-lane store groups and 32-lane load groups of the yz-plane stage hit distinct banks)
+// ---- apply_planes3 (mfgpu_kernels_p.hip): a wave owns 64 / n cells (n lanes per cell).  A batch's dof list has a
+// FIXED structure of 64-lane slots: p_ji(n) slots of interior dofs (stored to dst by the cell loop) followed by
+// p_hs(n) slots of pass-2 dofs (partial sums to the halo buffer), sized for the most compact batch of 64 / n cells
+// (3x2x2 cells at p = 4: 539 interior, 514 surface dofs).  Cells of the LDS transpose arrays are p_cell_stride(n)
+// values apart (stride = n mod 32: the 16-lane store groups and 32-lane load groups of the yz-plane stage hit
+// distinct banks).
 constexpr int p_cells_per_wave(int n) { return 64 / n; }
-constexpr int p_kgu(int n) { return n == 2 ? 2 : n == 3 ? 5 : n == 4 ? 11 : n == 5 ? 17 : n == 6 ? 24 : 35; }
+constexpr int p_ji(int n) { return n == 3 ? 2 : n == 4 ? 5 : 9; }
+constexpr int p_hs(int n) { return n == 3 ? 3 : n == 4 ? 6 : 9; }
+constexpr int p_kgu(int n) { return p_ji(n) + p_hs(n); }
 constexpr int p_cell_stride(int n) {
   int s = n * n * n;
   while ((s & 31) != (n & 31)) ++s;
@@ -64,9 +69,10 @@ struct Plan {
 // default_batch_limits): apply_planes3 processes a batch in one pass of one wave.
 struct PlanLimits {
   uint32_t max_cells = 0, max_dofs = 0;
-  // > 0: the interior (stored-by-the-cell-loop) dofs of every batch fill whole slots of this many entries and
-  // contain no constrained dof; the rest takes the pass-2 route; halo regions are padded to whole slots
-  uint32_t slot_align = 0;
+  // > 0 (apply_planes3): at most interior_max dofs of a batch stay on the interior route (stored by the cell loop,
+  // never constrained); the rest -- at most shared_max, else the plan fails with MFGPU_EUNSUPPORTED -- takes the
+  // pass-2 route, and every batch has at least one pass-2 dof; every batch owns halo_stride halo slots
+  uint32_t interior_max = 0, shared_max = 0, halo_stride = 0;
 };
 
 // Build the plan from a description (validates it).  Returns 0 or MFGPU_E*.

@@ -18,11 +18,9 @@ struct ApplyArgs {
   const uint16_t *lmapx;  // apply_batches_x: x-pencil index runs padded to 32-bit words, or nullptr
   const uint16_t *perm;   // apply_batches_x: [2][256] lane -> pencil id of the y- and the z-stage, or nullptr (natural)
   // apply_planes3: fixed-size per-batch records (nullptr otherwise)
-  const uint4 *metap;      // {cells, dofs, interior dofs, first halo slot}
-  const uint32_t *bdofsp;  // [p_kgu(n) * 64] dof list, padded with its last entry
+  const uint32_t *bdofsp;  // [p_kgu(n) * 64] dof list: p_ji(n) slots of interior dofs, p_hs(n) slots of pass-2 dofs
   const uint32_t *idxp;    // [(n*n+1)/2 words][NT tasks] packed 16-bit byte offsets into the batch array
   const T *coefp;          // [n*n rows][NT tasks] folded coefficient
-  uint32_t halo_slots;     // halo[halo_slots .. +64) is the sink of the padding slots' stores
   const T *coef;          // folded a*J0^2*JxW (apply_batches_g: the 6 entries of a*JxW*J*J^T), plan cell order
   const uint32_t *cmask;  // plan cell order, or nullptr
   const T *hn_weights;    // [n*n] W[i*n+j] (device), or nullptr

@@ -148,7 +148,9 @@ apply_planes3(const ApplyArgs<T> A, const TablesEO<T, n> tab) {
   constexpr int n2 = n * n;
   constexpr int CW = p_cells_per_wave(n);  // cells per wave
   constexpr int NT = CW * n;               // tasks (active lanes) of a full batch
-  constexpr int KGU = p_kgu(n);            // 64-lane slots of a batch's dof list
+  constexpr int KGU = p_kgu(n);            // 64-lane slots of a batch's dof list:
+  constexpr int JI = p_ji(n);              //   JI slots of interior dofs, then HS = KGU - JI slots of pass-2 dofs
+  constexpr int HS = KGU - JI;
   constexpr int SA = p_cell_stride(n);     // padded cell stride of the transpose arrays
   constexpr int NIW = (n2 + 1) / 2;        // 32-bit words of a task's packed index run
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
@@ -186,21 +188,10 @@ apply_planes3(const ApplyArgs<T> A, const TablesEO<T, n> tab) {
   if (b >= bend) return;
   auto next_of = [&](uint32_t x) { return x + bstride < bend ? x + bstride : x; };
 
-  // Per-batch records have FIXED strides (mfgpu_api.hip): every address below is a uniform base (scalar arithmetic
-  // on the batch index) plus a lane offset plus an immediate; nothing is clamped per batch and no load depends on
-  // another batch's metadata.  Vectors and the halo buffer are addressed base + 32-bit byte offset (the plan
-  // guarantees n_dofs < 2^29; shifting a dof-list entry left by 3 also drops its flag bit 31).
-  struct Meta {
-    int nb, nint;
-    uint32_t hoff;
-  };
-  auto meta_of = [&](const uint4 &r) {
-    Meta m;
-    m.nb = __builtin_amdgcn_readfirstlane((int)r.y);
-    m.nint = __builtin_amdgcn_readfirstlane((int)r.z);
-    m.hoff = (uint32_t)__builtin_amdgcn_readfirstlane((int)r.w);
-    return m;
-  };
+  // Per-batch records have FIXED sizes and a fixed structure (mfgpu_api.hip): every address below is a uniform base
+  // (scalar arithmetic on the batch index) plus a lane offset plus an immediate; nothing is clamped per batch and
+  // there is no per-batch metadata at all.  Vectors and the halo buffer are addressed base + 32-bit byte offset
+  // (the plan guarantees n_dofs < 2^29; shifting a dof-list entry left by 3 also drops its flag bit 31).
   auto load_dofs = [&](uint32_t bb, uint32_t (&g)[KGU]) {
     const uint32_t *p = A.bdofsp + (size_t)bb * (KGU * 64) + lane;
 #pragma unroll
@@ -224,46 +215,31 @@ apply_planes3(const ApplyArgs<T> A, const TablesEO<T, n> tab) {
   auto stage_src = [&](const uint32_t (&g)[KGU], const T (&sv)[KGU]) {
 #pragma unroll
     for (int j = 0; j < KGU; ++j) {
-      // value & ~(sign of g): bit arithmetic instead of a select, which hipcc turns into a branch per slot
-      const unsigned long long keep = (unsigned long long)(long long)~((int)g[j] >> 31);
-      const double v = (double)sv[j];
-      ua[lane + j * 64] = __longlong_as_double((long long)((unsigned long long)__double_as_longlong(v) & keep));
+      double v = (double)sv[j];
+      if (j >= JI) {  // constrained dofs sit in the pass-2 slots only
+        // value & ~(sign of g): bit arithmetic instead of a select, which hipcc turns into a branch per slot
+        const unsigned long long keep = (unsigned long long)(long long)~((int)g[j] >> 31);
+        v = __longlong_as_double((long long)((unsigned long long)__double_as_longlong(v) & keep));
+      }
+      ua[lane + j * 64] = v;
     }
   };
   // byte offset into ua of entry i = x + n * y of this task's index run (stored pre-multiplied by 8)
   auto ixb = [&](const uint32_t (&ix)[NIW], int i) -> uint32_t {
     return (i & 1) ? (ix[i >> 1] >> 16) : (ix[i >> 1] & 0xffffu);
   };
-  // scatter (distribute_local_to_global, fee_gpu.cuh:346-363), ONE wave-wide store per 64-lane slot and no per-lane
-  // case: the plan (PlanLimits::slot_align) makes the interior dofs of a batch -- its alone, final, never constrained
-  // -- fill whole slots; the slots behind them are partial sums for pass 2 and go to the batch's contiguous, slot-
-  // padded halo region; the slots behind those are padding and go to a sink behind the halo buffer.  The three cases
-  // are wave-uniform: scalar selects of base and offset, no branch (a branch here would let the compiler sink the
-  // contractions of the surrounding steps past the stores).
-  // Per batch three lane values -- (nint - lane), (nb - lane) and the lane's first halo byte offset -- made opaque
-  // to the optimizer; per slot the class falls out of two compares with an immediate.  (Computing the classes from
-  // the scalars nint / nb instead makes hipcc hoist all 17 slots' scalar selects to the top of the iteration and
-  // spill them to VGPR lanes: +140 lane reads / writes per batch.)
-  struct ScatterLane {
-    int d_int, d_all;
-    uint32_t hoff;
-  };
-  auto scatter_lane = [&](const Meta &m) {
-    ScatterLane sl;
-    sl.d_int = m.nint - lane;
-    sl.d_all = m.nb - lane;
-    sl.hoff = (m.hoff - (uint32_t)m.nint + (uint32_t)lane) * (uint32_t)sizeof(T);
-    asm volatile("" : "+v"(sl.d_int), "+v"(sl.d_all), "+v"(sl.hoff));
-    return sl;
-  };
-  const uint32_t sink_off = (A.halo_slots + (uint32_t)lane) * (uint32_t)sizeof(T);
-  auto scatter_slot = [&](int j, const ScatterLane &sl, uint32_t g, T r, T oldv) {
-    int di = sl.d_int, da = sl.d_all;
-    asm volatile("" : "+v"(di), "+v"(da));  // pins the slot's compares and selects HERE (see above)
-    const bool iv = di > 64 * j, nv = da <= 64 * j;  // the same for every lane
-    char *const base = __ballot(iv) != 0 ? reinterpret_cast<char *>(A.dst) : reinterpret_cast<char *>(A.halo);
-    const uint32_t voff = iv ? g * (uint32_t)sizeof(T) : nv ? sink_off : sl.hoff + (uint32_t)(64 * j * (int)sizeof(T));
-    *reinterpret_cast<T *>(base + voff) = (ADD && iv) ? oldv + r : r;
+  // scatter (distribute_local_to_global, fee_gpu.cuh:346-363), ONE wave-wide store per 64-lane slot and no case
+  // distinction at run time: the first JI slots hold interior dofs -- the batch's alone, final, never constrained --
+  // and go to dst (padding lanes store the 0 of their untouched accumulator slot, or old + 0, to a pass-2 dof of the
+  // batch, which pass 2 rewrites); the other HS slots are partial sums for pass 2 and go to the batch's HS * 64 halo
+  // slots (padding lanes: unused halo slots).
+  auto scatter_slot = [&](int j, uint32_t bb, uint32_t g, T r, T oldv) {
+    if (j < JI) {
+      *dst_at(g) = ADD ? oldv + r : r;
+    } else {
+      T *const hp = A.halo + (size_t)bb * (HS * 64) + lane;
+      hp[(j - JI) * 64] = r;  // (constrained dofs: value ignored by pass 2)
+    }
   };
 
   uint32_t b1 = next_of(b), b2 = next_of(b1);
@@ -271,7 +247,6 @@ apply_planes3(const ApplyArgs<T> A, const TablesEO<T, n> tab) {
   uint32_t IXc[NIW], IXn[NIW];
   T Cc[n2];
   T SVn[KGU], R[KGU], old[KGU];
-  Meta mp = {0, 0, 0u} /* no previous batch yet: every slot of its scatter is padding */, mc = meta_of(A.metap[b]), mn = meta_of(A.metap[b1]);
   load_dofs(b, Gc);
   load_dofs(b1, Gn);
   load_ix(b, IXc);
@@ -297,6 +272,10 @@ apply_planes3(const ApplyArgs<T> A, const TablesEO<T, n> tab) {
   // LDS bases of this task: xy-plane with z = k (stages A, C) and yz-plane with x = k (stage B)
   const int pxy = lc * SA + n2 * k;  // + x + n * y
   const int pyz = lc * SA + k;       // + n * y + n2 * z
+  // the batch whose results wait in R for their deferred scatter.  (First iteration: this batch itself with R = 0 --
+  // zeros, or old + 0, go where the real results follow one iteration later; a condition here would be a branch, and
+  // hipcc merges the branches of neighbouring steps by moving the contractions between them out of the way.)
+  uint32_t bp = b;
 
   while (true) {
     const bool has_next = b1 != b;
@@ -305,13 +284,12 @@ apply_planes3(const ApplyArgs<T> A, const TablesEO<T, n> tab) {
 #ifdef MFGPU_STAMPS
     if (A.stamps && threadIdx.x == 0) A.stamps[(size_t)b * 16 + 10] = blockIdx.x + 1;
 #endif
-    // ---- coalesced loads of the coming batches: metadata and dof list two ahead, index runs one ahead
-    const uint4 mraw = A.metap[b2];
+    // ---- coalesced loads of the coming batches: dof list two ahead, index runs one ahead
     load_dofs(b2, Gnn);
     load_ix(b1, IXn);
     if (ADD) {
 #pragma unroll
-      for (int j = 0; j < KGU; ++j) old[j] = *dst_at(Gp[j]);
+      for (int j = 0; j < JI; ++j) old[j] = *dst_at(Gp[j]);
     }
     STAMP(1);
     // The scattered accesses (gather of the next batch's source values, stores of the PREVIOUS batch's results) and
@@ -323,11 +301,11 @@ apply_planes3(const ApplyArgs<T> A, const TablesEO<T, n> tab) {
       for (int j = (KGU * s) / (2 * n); j < (KGU * (s + 1)) / (2 * n); ++j) SVn[j] = src_at(Gn[j]);
       MFGPU_PIN_VMEM();
     };
-    const ScatterLane slp = scatter_lane(mp);
     auto hookB = [&](int s) {  // 5 n steps: the previous batch's scatter
       MFGPU_PIN_VMEM();
 #pragma unroll
-      for (int j = (KGU * s) / (5 * n); j < (KGU * (s + 1)) / (5 * n); ++j) scatter_slot(j, slp, Gp[j], R[j], old[j]);
+      for (int j = (KGU * s) / (5 * n); j < (KGU * (s + 1)) / (5 * n); ++j)
+        scatter_slot(j, bp, Gp[j], R[j], old[j]);
       MFGPU_PIN_VMEM();
     };
     const T *const cnext = A.coefp + (size_t)b1 * (n2 * NT) + tk;
@@ -502,7 +480,7 @@ apply_planes3(const ApplyArgs<T> A, const TablesEO<T, n> tab) {
     STAMP(5);
     stage_src(Gn, SVn);  // (after the last batch: its own values again, unused)
     STAMP(6);
-    mp = mc;
+    bp = b;
 #pragma unroll
     for (int j = 0; j < KGU; ++j) Gp[j] = Gc[j];
     STAMP(7);
@@ -512,8 +490,6 @@ apply_planes3(const ApplyArgs<T> A, const TablesEO<T, n> tab) {
     b = b1;
     b1 = b2;
     b2 = next_of(b2);
-    mc = mn;
-    mn = meta_of(mraw);
 #pragma unroll
     for (int j = 0; j < KGU; ++j) {
       Gc[j] = Gn[j];
@@ -525,11 +501,10 @@ apply_planes3(const ApplyArgs<T> A, const TablesEO<T, n> tab) {
   // the last batch's results
   if (ADD) {
 #pragma unroll
-    for (int j = 0; j < KGU; ++j) old[j] = *dst_at(Gp[j]);
+    for (int j = 0; j < JI; ++j) old[j] = *dst_at(Gp[j]);
   }
-  const ScatterLane sll = scatter_lane(mp);
 #pragma unroll
-  for (int j = 0; j < KGU; ++j) scatter_slot(j, sll, Gp[j], R[j], old[j]);
+  for (int j = 0; j < KGU; ++j) scatter_slot(j, bp, Gp[j], R[j], old[j]);
 }
 
 template <int n, typename T>

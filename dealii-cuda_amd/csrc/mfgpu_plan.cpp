@@ -227,7 +227,7 @@ int build_plan(const mfgpu_desc &d, Plan &P, uint32_t max_chunks, const PlanLimi
       next = best;
     }
   }
-  const uint32_t nb = (uint32_t)batches.size();
+  uint32_t nb = (uint32_t)batches.size();
   // cells with a hanging-node mask first: the kernel takes the extra interpolation stages for a whole
   // chunk of cells as soon as one of them is masked, so masked cells should share chunks
   if ((d.flags & MFGPU_HANGING_NODES) && d.constraint_mask)
@@ -236,43 +236,69 @@ int build_plan(const mfgpu_desc &d, Plan &P, uint32_t max_chunks, const PlanLimi
 
   // ---- per batch: unique dofs, ordered [interior ascending | shared] where interior = touched by this
   // batch only (the shared part is re-ordered by toucher group below)
-  std::vector<std::vector<uint32_t>> bd(nb);
-  std::vector<uint32_t> ntouch(N, 0);
-  for (uint32_t b = 0; b < nb; ++b) {
-    std::vector<uint32_t> &v = bd[b];
-    v.reserve(batches[b].size() * nd);
-    for (uint32_t c : batches[b])
-      for (uint32_t i = 0; i < nd; ++i) v.push_back(l2g[(uint64_t)c * nd + i]);
-    std::sort(v.begin(), v.end());
-    v.erase(std::unique(v.begin(), v.end()), v.end());
-    if (v.size() > NBmax || v.size() > 8191u) {
-      // (the greedy estimate nd - gain under-counts a cell that lists one dof twice; the kernels hold a batch's
-      // dofs in a fixed number of register / LDS slots and byte offsets of batch-local ids in 16 bits)
-      set_error("internal: batch exceeds the kernel's dof slots (degenerate loc2glob?)");
-      return MFGPU_EINVAL;
+  //
+  // A dof takes the pass-2 route ("shared") if two or more batches touch it.  With limits->interior_max
+  // (apply_planes3: fixed slot structure of the batch dof list, no per-lane case distinction in the scatter) more
+  // dofs are DEMOTED to that route although only this batch touches them (one partial sum; pass 2 copies it):
+  // constrained dofs -- pass 2 writes the identity row of every constrained dof it lists, so the cell loop never
+  // stores to one --, the interior dofs beyond interior_max, and one dof if the batch would otherwise have no pass-2
+  // dof at all (the padding entries of the interior slots store a zero to a pass-2 dof of the batch).  A batch with
+  // more than shared_max pass-2 dofs (the growth above only bounds the total) is split in two and everything is
+  // classified again.
+  const uint32_t interior_max = limits ? limits->interior_max : 0u;
+  std::vector<std::vector<uint32_t>> bd;
+  std::vector<uint32_t> ntouch, nint;
+  std::vector<uint8_t> shared_flag;
+  for (;;) {
+    nb = (uint32_t)batches.size();
+    bd.assign(nb, {});
+    ntouch.assign(N, 0);
+    for (uint32_t b = 0; b < nb; ++b) {
+      std::vector<uint32_t> &v = bd[b];
+      v.reserve(batches[b].size() * nd);
+      for (uint32_t c : batches[b])
+        for (uint32_t i = 0; i < nd; ++i) v.push_back(l2g[(uint64_t)c * nd + i]);
+      std::sort(v.begin(), v.end());
+      v.erase(std::unique(v.begin(), v.end()), v.end());
+      if (v.size() > NBmax || v.size() > 8191u) {
+        // (the greedy estimate nd - gain under-counts a cell that lists one dof twice; the kernels hold a batch's
+        // dofs in a fixed number of register / LDS slots and byte offsets of batch-local ids in 16 bits)
+        set_error("internal: batch exceeds the kernel's dof slots (degenerate loc2glob?)");
+        return MFGPU_EINVAL;
+      }
+      for (uint32_t g : v) ntouch[g]++;
     }
-    for (uint32_t g : v) ntouch[g]++;
-  }
-  // A dof takes the pass-2 route ("shared") if two or more batches touch it.  With limits->slot_align (apply_planes3:
-  // 64, one wave-wide store per slot, no per-lane case distinction) two more kinds are DEMOTED to that route although
-  // only this batch touches them (one partial sum; pass 2 copies it): constrained dofs -- pass 2 writes the identity
-  // row of every constrained dof it lists, so the cell loop never stores to one -- and the last (count mod slot_align)
-  // interior dofs, so that the interior part of every batch fills whole slots.
-  const uint32_t slot_align = limits ? limits->slot_align : 0u;
-  std::vector<uint8_t> shared_flag(N, 0);
-  for (uint32_t g = 0; g < N; ++g) shared_flag[g] = ntouch[g] >= 2 || (slot_align && ntouch[g] == 1 && constrained[g]);
-  std::vector<uint32_t> nint(nb, 0);
-  for (uint32_t b = 0; b < nb; ++b) {
-    std::vector<uint32_t> &v = bd[b];
-    std::stable_partition(v.begin(), v.end(), [&](uint32_t g) { return !shared_flag[g]; });
-    uint32_t k = 0;
-    while (k < v.size() && !shared_flag[v[k]]) ++k;
-    if (slot_align) {
-      const uint32_t keep = k - k % slot_align;
-      for (uint32_t t = keep; t < k; ++t) shared_flag[v[t]] = 1;
-      k = keep;
+    shared_flag.assign(N, 0);
+    for (uint32_t g = 0; g < N; ++g)
+      shared_flag[g] = ntouch[g] >= 2 || (interior_max && ntouch[g] == 1 && constrained[g]);
+    nint.assign(nb, 0);
+    std::vector<uint32_t> too_big;
+    for (uint32_t b = 0; b < nb; ++b) {
+      std::vector<uint32_t> &v = bd[b];
+      std::stable_partition(v.begin(), v.end(), [&](uint32_t g) { return !shared_flag[g]; });
+      uint32_t k = 0;
+      while (k < v.size() && !shared_flag[v[k]]) ++k;
+      if (interior_max) {
+        uint32_t keep = std::min(k, interior_max);
+        if (keep == v.size() && keep > 0) --keep;
+        for (uint32_t t = keep; t < k; ++t) shared_flag[v[t]] = 1;
+        k = keep;
+        if (v.size() - k > limits->shared_max) too_big.push_back(b);
+      }
+      nint[b] = k;
     }
-    nint[b] = k;
+    if (too_big.empty()) break;
+    for (size_t i = too_big.size(); i-- > 0;) {  // back to front: indices stay valid
+      const uint32_t b = too_big[i];
+      if (batches[b].size() < 2) {
+        set_error("one cell has more pass-2 dofs than the plane kernel's dof-list slots hold");
+        return MFGPU_EUNSUPPORTED;
+      }
+      const size_t half = batches[b].size() / 2;
+      std::vector<uint32_t> second(batches[b].begin() + half, batches[b].end());
+      batches[b].resize(half);
+      batches.insert(batches.begin() + b + 1, std::move(second));
+    }
   }
 
   // ---- greedy colouring of batches (conflict = shared dof)
@@ -371,12 +397,8 @@ int build_plan(const mfgpu_desc &d, Plan &P, uint32_t max_chunks, const PlanLimi
     const uint32_t b = order[k];
     const std::vector<uint32_t> &v = bd[b];
     P.batch_nint.push_back(nint[b]);
-    {
-      // (slot_align: the kernel stores whole slots, so a batch's halo region is padded to whole slots too)
-      uint32_t nsh = (uint32_t)(v.size() - nint[b]);
-      if (slot_align) nsh = (nsh + slot_align - 1) / slot_align * slot_align;
-      P.halo_off.push_back(P.halo_off.back() + nsh);
-    }
+    // (apply_planes3: every batch owns a fixed number of halo slots, so a slot index follows from the batch index)
+    P.halo_off.push_back(P.halo_off.back() + (interior_max ? limits->halo_stride : (uint32_t)(v.size() - nint[b])));
     for (uint32_t g : v) {
       uint8_t f = 0;
       if (constrained[g]) f |= kFlagConstrained;
