@@ -50,13 +50,9 @@ struct mfgpu_handle {
   unsigned long long *d_stamps = nullptr;  // diagnostic build only
   size_t lds = 0, device_bytes = 0;
   uint32_t max_grid = 0;  // resident workgroups of the cell-loop kernel
-  int stagger = 0;        // see apply_batches
-  bool plane = false;     // experimental plane-per-thread kernel (apply_planes)
-  bool ls = false;        // loader / compute specialised cell loop (apply_batches_ls)
   bool xk = false;        // 3D two-pass kernel for three workgroups per CU (apply_batches_x)
   bool gk = false;        // general-Jacobian kernel (apply_batches_g)
   bool pk = false;        // plane-per-thread kernel (apply_planes3): 3D uniform-Jacobian default for p = 2..4
-  bool wave = false;      // wave-granular cell phase (apply_batches<..., WAVE = true>)
   // profiling
   bool prof = false;
   std::vector<hipEvent_t> ev;  // start/stop pairs
@@ -119,7 +115,7 @@ int create_typed(mfgpu_handle *h, const mfgpu_desc &d) {
   if ((rc = dev_upload(&h->d_bdofs, P.bdofs.data(), P.bdofs.size() * 4, acct))) return rc;
   if ((rc = dev_upload(&h->d_bflags, P.bflags.data(), P.bflags.size(), acct))) return rc;
   if ((rc = dev_upload(&h->d_lmap, P.lmap.data(), P.lmap.size() * 2, acct))) return rc;
-  if (h->xk && !h->hn && !getenv("MFGPU_NOPERM")) {
+  if (h->xk && !h->hn) {
     // Lane -> pencil maps of the y- and z-stage (see apply_batches_x).  LDS rules (MI355X_MICROARCH.md): a
     // ds_read_b64 is served in 32-lane groups, a double occupies slot (index mod 32); ds_write_b64 / ds_read2_b64
     // in 16-lane groups, slot (index mod 16).  All n elements of a pencil shift its base by the same stride, so
@@ -305,90 +301,33 @@ int create_typed(mfgpu_handle *h, const mfgpu_desc &d) {
     h->max_grid = (uint32_t)(per_cu < 1 ? 1 : per_cu) * (uint32_t)prop.multiProcessorCount;
     return 0;
   }
-  if (h->plane) {
-    ApplyArgs<T> dummy{};
-    dummy.nb_max = P.max_batch_dofs;
-    int per_cu = 0, dev = 0;
-    hipDeviceProp_t prop;
-    HIP_TRY(plane_launch<T>(P.n, dummy, nullptr, nullptr, 0, nullptr, true, &h->lds, &per_cu));
-    HIP_TRY(hipGetDevice(&dev));
-    HIP_TRY(hipGetDeviceProperties(&prop, dev));
-    h->max_grid = (uint32_t)(per_cu < 1 ? 1 : per_cu) * (uint32_t)prop.multiProcessorCount;
-    if (const char *e = getenv("MFGPU_GRID"))
-      if (atoi(e) > 0) h->max_grid = (uint32_t)atoi(e);
-    return 0;
-  }
+  // persistent grid: as many workgroups as fit on the chip (each loops over its batches)
+  ApplyArgs<T> dummy{};
+  dummy.nb_max = P.max_batch_dofs;
+  int per_cu = 0, dev = 0;
+  hipDeviceProp_t prop;
   if (h->gk) {
-    ApplyArgs<T> dummy{};
-    dummy.nb_max = P.max_batch_dofs;
-    int per_cu = 0, dev = 0;
-    hipDeviceProp_t prop;
     HIP_TRY(g_launch<T>(P.n, dummy, nullptr, nullptr, h->hn, 0, nullptr, true, &h->lds, nullptr));
-    if (h->lds > 160 * 1024) {
-      set_error("batch needs more than 160 KiB of LDS; lower max_dofs_per_batch");
-      return MFGPU_EINVAL;
-    }
-    HIP_TRY(g_launch<T>(P.n, dummy, nullptr, nullptr, h->hn, 0, nullptr, true, &h->lds, &per_cu));
-    HIP_TRY(hipGetDevice(&dev));
-    HIP_TRY(hipGetDeviceProperties(&prop, dev));
-    h->max_grid = (uint32_t)(per_cu < 1 ? 1 : per_cu) * (uint32_t)prop.multiProcessorCount;
-    if (const char *e2 = getenv("MFGPU_GRID"))
-      if (atoi(e2) > 0) h->max_grid = (uint32_t)atoi(e2);
-    return 0;
-  }
-  if (h->xk) {
-    ApplyArgs<T> dummy{};
-    dummy.nb_max = P.max_batch_dofs;
-    int per_cu = 0, dev = 0;
-    hipDeviceProp_t prop;
+  } else if (h->xk) {
     HIP_TRY(x_launch<T>(P.n, dummy, nullptr, nullptr, h->hn, 0, nullptr, true, &h->lds, nullptr));
-    if (h->lds > 160 * 1024) {
-      set_error("batch needs more than 160 KiB of LDS; lower max_dofs_per_batch");
-      return MFGPU_EINVAL;
-    }
-    HIP_TRY(x_launch<T>(P.n, dummy, nullptr, nullptr, h->hn, 0, nullptr, true, &h->lds, &per_cu));
-    HIP_TRY(hipGetDevice(&dev));
-    HIP_TRY(hipGetDeviceProperties(&prop, dev));
-    h->max_grid = (uint32_t)(per_cu < 1 ? 1 : per_cu) * (uint32_t)prop.multiProcessorCount;
-    if (const char *e = getenv("MFGPU_GRID"))
-      if (atoi(e) > 0) h->max_grid = (uint32_t)atoi(e);
-    return 0;
+  } else {
+    h->lds = apply_lds_bytes<T>(P.dim, P.n, P.max_batch_dofs);
   }
-  if (h->ls) {
-    ApplyArgs<T> dummy{};
-    dummy.nb_max = P.max_batch_dofs;
-    int per_cu = 0, dev = 0;
-    hipDeviceProp_t prop;
-    HIP_TRY(ls_launch<T>(P.dim, P.n, dummy, nullptr, nullptr, h->hn, 0, nullptr, true, &h->lds, nullptr));
-    if (h->lds > 160 * 1024) {
-      set_error("batch needs more than 160 KiB of LDS; lower max_dofs_per_batch");
-      return MFGPU_EINVAL;
-    }
-    HIP_TRY(ls_launch<T>(P.dim, P.n, dummy, nullptr, nullptr, h->hn, 0, nullptr, true, &h->lds, &per_cu));
-    HIP_TRY(hipGetDevice(&dev));
-    HIP_TRY(hipGetDeviceProperties(&prop, dev));
-    h->max_grid = (uint32_t)(per_cu < 1 ? 1 : per_cu) * (uint32_t)prop.multiProcessorCount;
-    if (const char *e = getenv("MFGPU_GRID"))
-      if (atoi(e) > 0) h->max_grid = (uint32_t)atoi(e);
-    return 0;
-  }
-  h->lds = apply_lds_bytes<T>(P.dim, P.n, P.max_batch_dofs, h->wave);
   if (h->lds > 160 * 1024) {
     set_error("batch needs more than 160 KiB of LDS; lower max_dofs_per_batch");
     return MFGPU_EINVAL;
   }
-  HIP_TRY(apply_configure<T>(P.dim, P.n, h->lds, h->wave));
-  // persistent grid: as many workgroups as fit on the chip (each loops over its batches)
-  int per_cu = 0, dev = 0;
-  hipDeviceProp_t prop;
-  HIP_TRY(apply_occupancy<T>(P.dim, P.n, h->hn, h->twopass, h->wave, h->lds, &per_cu));
+  if (h->gk) {
+    HIP_TRY(g_launch<T>(P.n, dummy, nullptr, nullptr, h->hn, 0, nullptr, true, &h->lds, &per_cu));
+  } else if (h->xk) {
+    HIP_TRY(x_launch<T>(P.n, dummy, nullptr, nullptr, h->hn, 0, nullptr, true, &h->lds, &per_cu));
+  } else {
+    HIP_TRY(apply_configure<T>(P.dim, P.n, h->lds));
+    HIP_TRY(apply_occupancy<T>(P.dim, P.n, h->hn, h->twopass, h->lds, &per_cu));
+  }
   HIP_TRY(hipGetDevice(&dev));
   HIP_TRY(hipGetDeviceProperties(&prop, dev));
-  if (per_cu < 1) per_cu = 1;
-  h->max_grid = (uint32_t)per_cu * (uint32_t)prop.multiProcessorCount;
-  if (const char *e = getenv("MFGPU_STAGGER")) h->stagger = atoi(e);
-  if (const char *e = getenv("MFGPU_GRID"))
-    if (atoi(e) > 0) h->max_grid = (uint32_t)atoi(e);  // tuning experiments only
+  h->max_grid = (uint32_t)(per_cu < 1 ? 1 : per_cu) * (uint32_t)prop.multiProcessorCount;
   return 0;
 }
 
@@ -416,7 +355,6 @@ int vmult_typed(mfgpu_handle *h, void *dst, const void *src, hipStream_t st, int
   a.src = (const T *)src;
   a.nb_max = P.max_batch_dofs;
   a.add = add;
-  a.stagger = h->stagger;
   a.stamps = h->d_stamps;
   a.dbg = 0;
 #ifdef MFGPU_STAMPS
@@ -449,15 +387,9 @@ int vmult_typed(mfgpu_handle *h, void *dst, const void *src, hipStream_t st, int
     else if (h->xk)
       HIP_TRY(x_launch<T>(P.n, a, h->S.data(), h->Dt.data(), h->hn, nbat < h->max_grid ? nbat : h->max_grid, st,
                           false, nullptr, nullptr));
-    else if (h->ls)
-      HIP_TRY(ls_launch<T>(P.dim, P.n, a, h->S.data(), h->Dt.data(), h->hn, nbat < h->max_grid ? nbat : h->max_grid,
-                           st, false, nullptr, nullptr));
-    else if (h->plane)
-      HIP_TRY(plane_launch<T>(P.n, a, h->S.data(), h->Dt.data(), nbat < h->max_grid ? nbat : h->max_grid, st,
-                              false, nullptr, nullptr));
     else
-    HIP_TRY(apply_launch<T>(P.dim, P.n, a, h->S.data(), h->Dt.data(), h->hn, h->twopass, h->wave,
-                            nbat < h->max_grid ? nbat : h->max_grid, st));
+      HIP_TRY(apply_launch<T>(P.dim, P.n, a, h->S.data(), h->Dt.data(), h->hn, h->twopass,
+                              nbat < h->max_grid ? nbat : h->max_grid, st));
     if (h->prof) {
       HIP_TRY(hipEventRecord(h->ev[h->ev_used + 1], st));
       h->ev_used += 2;
@@ -568,43 +500,31 @@ int mfgpu_create(const mfgpu_desc *desc, mfgpu_handle **out) {
     return MFGPU_EINVAL;
   }
   mfgpu_handle *h = new mfgpu_handle();
-  mfgpu_desc dplan = d;
-  if (const char *e = getenv("MFGPU_WAVE")) h->wave = atoi(e) != 0;  // tuning experiments
-  if (const char *e = getenv("MFGPU_PLANE"))
-    h->plane = atoi(e) != 0 && d.dim == 3 && d.degree <= 4 && !(d.flags & MFGPU_HANGING_NODES) &&
-               !(d.flags & MFGPU_COLORED_SCATTER);
-  if (h->plane) {  // one wave per batch, one pass of 64/n cells, <= 1088 dofs
-    h->wave = false;
-    dplan.max_dofs_per_batch = 1088;
-    dplan.max_cells_per_batch = 64u / (uint32_t)(d.degree + 1);
+  // Kernel family (mfgpu_desc.kernel; 0 = the library's choice):
+  //   apply_planes3   3D, uniform-Jacobian path, conforming mesh, two-pass mode, p = 2..4
+  //   apply_batches_x 3D two-pass otherwise (hanging nodes, p = 1, 5, 6)
+  //   apply_batches   2D, and the coloured-scatter mode
+  //   apply_batches_g the general-Jacobian path (no MFGPU_UNIFORM_J0)
+  const bool colored = (d.flags & MFGPU_COLORED_SCATTER) != 0;
+  if (d.kernel > MFGPU_KERNEL_PLANES) {
+    set_error("unknown mfgpu_desc.kernel");
+    delete h;
+    return MFGPU_EINVAL;
   }
-  if (h->wave) {  // one wave per batch: smaller batches (<= 768 dofs pass through 64 x 12 registers)
-    if (!dplan.max_dofs_per_batch || dplan.max_dofs_per_batch > 768) dplan.max_dofs_per_batch = 768;
-    if (!dplan.max_cells_per_batch) dplan.max_cells_per_batch = 8;
-  }
-  // experimental loader / compute wave split (slower than apply_batches: profiles/r01_notes.md)
-  if (const char *e = getenv("MFGPU_LS"))
-    h->ls = atoi(e) != 0 && !h->wave && !h->plane && !(d.flags & MFGPU_COLORED_SCATTER);
-  // apply_batches_x: 3D two-pass default, with and without hanging nodes (MFGPU_X=0: apply_batches)
-  h->xk = d.dim == 3 && !h->wave && !h->plane && !h->ls && !(d.flags & MFGPU_COLORED_SCATTER);
-  if (const char *e = getenv("MFGPU_X")) h->xk = h->xk && atoi(e) != 0;
-  if (general) {  // apply_batches_g is the only kernel of the general-Jacobian path
-    h->gk = true;
-    h->xk = h->wave = h->plane = h->ls = false;
-  }
-  // apply_planes3: 3D, uniform-Jacobian path, conforming meshes, two-pass mode, p = 2..4 (desc.kernel 0 or 3)
-  h->pk = d.dim == 3 && !general && !hn && !(d.flags & MFGPU_COLORED_SCATTER) && d.degree >= 2 && d.degree <= 4 &&
-          d.n_dofs < (1u << 29) &&  // vectors are addressed base + 32-bit byte offset
-          (d.kernel == MFGPU_KERNEL_AUTO || d.kernel == MFGPU_KERNEL_PLANES) && !h->wave && !h->plane && !h->ls;
-  if (d.kernel == MFGPU_KERNEL_PLANES && !h->pk) {
-    set_error("MFGPU_KERNEL_PLANES needs a 3D conforming uniform-Jacobian mesh, two-pass mode and degree 2..4");
+  h->gk = general;
+  const bool pk_ok = d.dim == 3 && !general && !hn && !colored && d.degree >= 2 && d.degree <= 4 &&
+                     d.n_dofs < (1u << 29);  // (vectors are addressed base + 32-bit byte offset)
+  const bool xk_ok = d.dim == 3 && !general && !colored;
+  if ((d.kernel == MFGPU_KERNEL_PLANES && !pk_ok) || (d.kernel == MFGPU_KERNEL_PENCILS_X && !xk_ok) ||
+      (d.kernel == MFGPU_KERNEL_PENCILS && general)) {
+    set_error("mfgpu_desc.kernel: this kernel family does not cover the description (see include/mfgpu.h)");
     delete h;
     return MFGPU_EUNSUPPORTED;
   }
-  if (d.kernel == MFGPU_KERNEL_PENCILS) h->xk = false;
+  h->pk = pk_ok && (d.kernel == MFGPU_KERNEL_AUTO || d.kernel == MFGPU_KERNEL_PLANES);
+  h->xk = xk_ok && !h->pk && d.kernel != MFGPU_KERNEL_PENCILS;
   PlanLimits lim;
   if (h->pk) {
-    h->xk = false;
     lim.max_cells = (uint32_t)p_cells_per_wave(d.degree + 1);
     lim.max_dofs = (uint32_t)p_kgu(d.degree + 1) * 64u - 1u;
     lim.interior_max = (uint32_t)p_ji(d.degree + 1) * 64u;
@@ -612,7 +532,15 @@ int mfgpu_create(const mfgpu_desc *desc, mfgpu_handle **out) {
     lim.shared_max = lim.halo_stride - 1u;  // the list's last slot stays padding (idle tasks)
   }
   // apply_batches_x unrolls 4 chunks at p=3 (64-cell batches = 13^3 dofs like p=4); everything else 3
-  int rc = build_plan(dplan, h->plan, (h->xk && d.degree == 3) ? 4u : 3u, h->pk ? &lim : nullptr);
+  int rc = build_plan(d, h->plan, (h->xk && d.degree == 3) ? 4u : 3u, h->pk ? &lim : nullptr);
+  if (rc == MFGPU_EUNSUPPORTED && h->pk && d.kernel == MFGPU_KERNEL_AUTO && xk_ok) {
+    // a cell with more surface dofs than the plane kernel's dof-list slots hold (cannot happen on conforming
+    // hexahedral meshes): the pencil kernel has no such limit
+    h->pk = false;
+    h->xk = true;
+    h->plan = Plan();
+    rc = build_plan(d, h->plan, d.degree == 3 ? 4u : 3u, nullptr);
+  }
   if (rc) {
     delete h;
     return rc;
@@ -725,7 +653,7 @@ int mfgpu_plan_stats(const mfgpu_handle *h, uint64_t s[8]) {
 
 const char *mfgpu_kernel_name(const mfgpu_handle *h) {
   if (!h) return "";
-  return h->pk ? "apply_planes3" : h->gk ? "apply_batches_g" : h->xk ? "apply_batches_x" : h->ls ? "apply_batches_ls" : h->plane ? "apply_planes" : "apply_batches";
+  return h->pk ? "apply_planes3" : h->gk ? "apply_batches_g" : h->xk ? "apply_batches_x" : "apply_batches";
 }
 
 int mfgpu_profile_enable(mfgpu_handle *h, int on) {

@@ -9,7 +9,7 @@
 
 #include <mutex>
 
-#include "mfgpu_cell.cuh"
+#include "mfgpu_cell.h"
 #include "mfgpu_kernels.h"
 
 namespace mfgpu {

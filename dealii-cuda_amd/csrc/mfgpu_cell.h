@@ -1,7 +1,7 @@
 // Device-side building blocks of the cell kernel, shared by the kernel translation units:
 // 1D table access, pencil mat-vecs, hanging-node pencil operations and the cell pipeline.
-#ifndef MFGPU_CELL_CUH
-#define MFGPU_CELL_CUH
+#ifndef MFGPU_CELL_H
+#define MFGPU_CELL_H
 
 #include <hip/hip_runtime.h>
 

@@ -16,7 +16,7 @@ struct ApplyArgs {
   const uint8_t *bflags;
   const uint16_t *lmap;
   const uint16_t *lmapx;  // apply_batches_x: x-pencil index runs padded to 32-bit words, or nullptr
-  const uint16_t *perm;   // apply_batches_x: [2][256] lane -> pencil id of the y- and the z-stage, or nullptr (natural)
+  const uint16_t *perm;   // apply_batches_x: [2][256] lane -> pencil id of the y- and the z-stage (nullptr: hanging nodes)
   // apply_planes3: fixed-size per-batch records (nullptr otherwise)
   const uint32_t *bdofsp;  // [p_kgu(n) * 64] dof list: p_ji(n) slots of interior dofs, p_hs(n) slots of pass-2 dofs
   const uint32_t *idxp;    // [(n*n+1)/2 words][NT tasks] packed 16-bit byte offsets into the batch array
@@ -33,7 +33,6 @@ struct ApplyArgs {
   uint32_t batch_end;  // one past the last batch of this launch
   uint32_t nb_max;  // LDS layout: max dofs per batch
   int add;          // vmult_add semantics
-  int stagger;      // start delay per resident-workgroup slot of a CU, in units of 8128 cycles
   unsigned long long *stamps;  // diagnostic build only (MFGPU_STAMPS), else nullptr
   int dbg;                     // diagnostic build only: ablation bits (1 cells, 2 gather, 4 scatter, 8 prefetch)
 };
@@ -46,30 +45,20 @@ struct Tables {
 };
 
 template <typename T>
-size_t apply_lds_bytes(int dim, int n, uint32_t nb_max, bool wave);
+size_t apply_lds_bytes(int dim, int n, uint32_t nb_max);
 template <typename T>
-hipError_t apply_configure(int dim, int n, size_t lds, bool wave);
+hipError_t apply_configure(int dim, int n, size_t lds);
 template <typename T>
 hipError_t apply_launch(int dim, int n, const ApplyArgs<T> &a, const double *S, const double *Dt,
-                        bool hn, bool twopass, bool wave, uint32_t grid, hipStream_t st);
+                        bool hn, bool twopass, uint32_t grid, hipStream_t st);
 template <typename T>
-hipError_t apply_occupancy(int dim, int n, bool hn, bool twopass, bool wave, size_t lds, int *blocks);
+hipError_t apply_occupancy(int dim, int n, bool hn, bool twopass, size_t lds, int *blocks);
 // pass 2, class-sorted structure-of-arrays form (mfgpu_pass2.hip)
 void build_pass2_classes(const std::vector<uint32_t> &sdofs, const std::vector<uint32_t> &s_off,
                          const std::vector<uint32_t> &s_idx, std::vector<uint32_t> &arr, std::vector<uint32_t> &tiles);
 template <typename T>
 hipError_t reduce_classes_launch(T *dst, const T *src, const T *halo, const uint32_t *arr, const uint32_t *tiles,
                                  uint32_t n_tiles, int add, hipStream_t st);
-template <typename T>
-hipError_t reduce_launch(T *dst, const T *src, const T *halo, const uint32_t *sdofs, const uint32_t *s_off,
-                         const uint32_t *s_idx, uint32_t ns, int add, hipStream_t st);
-template <typename T>
-hipError_t reduce_groups_launch(T *dst, const T *src, const T *halo, const uint32_t *sdofs, const uint32_t *chunks,
-                                const uint32_t *gstarts, uint32_t nchunks, int add, hipStream_t st);
-// experimental plane-per-thread kernel (3D, n <= 5, two-pass mode, no hanging nodes)
-template <typename T>
-hipError_t plane_launch(int n, const ApplyArgs<T> &a, const double *S, const double *Dt, uint32_t grid,
-                        hipStream_t st, bool configure_only, size_t *lds_out, int *occupancy);
 // 3D cell loop for three workgroups per CU (mfgpu_kernels_x.hip; two-pass mode)
 template <typename T>
 hipError_t x_launch(int n, const ApplyArgs<T> &a, const double *S, const double *Dt, bool hn, uint32_t grid,
@@ -88,10 +77,6 @@ hipError_t g_launch(int n, const ApplyArgs<T> &a, const double *S, const double 
 template <typename T>
 hipError_t fold_general_launch(T *M, const T *coef, const T *jxw, const T *jinv, const uint32_t *order,
                                uint32_t n_cells, uint32_t nd, hipStream_t st);
-// loader / compute specialised cell loop (mfgpu_kernels_ls.hip; two-pass mode)
-template <typename T>
-hipError_t ls_launch(int dim, int n, const ApplyArgs<T> &a, const double *S, const double *Dt, bool hn,
-                     uint32_t grid, hipStream_t st, bool configure_only, size_t *lds_out, int *occupancy);
 template <typename T>
 hipError_t orphan_launch(T *dst, const T *src, const uint32_t *orph, uint32_t n, int add, hipStream_t st);
 template <typename T>

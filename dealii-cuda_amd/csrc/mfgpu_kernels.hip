@@ -21,26 +21,22 @@
 // phi_i'(x_q) = sum_t phi_i(x_t) l_t'(x_q); it needs 4*dim contractions.
 #include <hip/hip_runtime.h>
 
-#include "mfgpu_cell.cuh"
+#include "mfgpu_cell.h"
 #include "mfgpu_kernels.h"
 
 namespace mfgpu {
 
-// WAVE = false: workgroup = 256 threads = 4 waves; they process CH = 256/P cells at a time and
-//               synchronise the transposes with s_barrier (250 of 256 lanes busy for p=4).
-// WAVE = true : workgroup = ONE wave with its own (smaller) batch: CH = 64/P cells at a time (2 for p=4,
-//               50 of 64 lanes busy); the transposes need only program order inside the wave and no wave
-//               ever waits for another one, so the waves of a CU sit in different phases (gather /
-//               cells / scatter) and memory latency overlaps with LDS and VALU work.
+// Workgroup = 256 threads = 4 waves; they process CH = 256/P cells at a time and synchronise the transposes with
+// s_barrier (250 of 256 lanes busy for p=4).
 // The hanging-node variant needs 258 VGPRs uncapped, one more allocation granule than two waves per
 // SIMD allow; LDS already limits the kernel to two workgroups per CU, so cap it there.
 template <int n>
 constexpr int min_waves_per_simd() { return n <= 5 ? 2 : 1; }
 
-template <int dim, int n, typename T, bool HN, bool TWOPASS, bool WAVE>
-__global__ void __launch_bounds__(WAVE ? 64 : 256) __attribute__((amdgpu_waves_per_eu(min_waves_per_simd<n>())))
+template <int dim, int n, typename T, bool HN, bool TWOPASS>
+__global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(min_waves_per_simd<n>())))
 apply_batches(const ApplyArgs<T> A, const Tables<T, n> tab) {
-  constexpr int kBlock = WAVE ? 64 : 256;
+  constexpr int kBlock = 256;
   constexpr int kGU = (max_batch_dofs(kBlock) + kBlock - 1) / kBlock;  // all gather loads of a batch in flight
   constexpr int nd = (dim == 3) ? n * n * n : n * n;
   constexpr int P = nd / n;          // pencils per cell
@@ -77,14 +73,6 @@ apply_batches(const ApplyArgs<T> A, const Tables<T, n> tab) {
     b = A.batch0 + (((G & 7u) == 0) ? (blockIdx.x & 7u) * (G >> 3) + (blockIdx.x >> 3) : blockIdx.x);
   }
   if (b >= bend) return;
-  // Stagger: all workgroups run batches of (nearly) identical length, so workgroups that start together
-  // stay phase-aligned (the whole CU gathers, then the whole CU computes) and the memory and compute
-  // phases never overlap.  Blocks are dealt round-robin over XCDs and CUs, so block b and b + 256 share a
-  // CU (speed only, never correctness): delay the k-th resident workgroup of a CU by k * stagger.
-  if (A.stagger > 0) {
-    const int slot = (int)((blockIdx.x / 256u) * 4u + ((blockIdx.x >> 3) & 3u));  // 8 phases chip-wide
-    for (int k = 0; k < slot * A.stagger; ++k) __builtin_amdgcn_s_sleep(70);  // 70 * 64 = 4480 cycles each
-  }
   uint32_t c0, d0, hoff;
   int nb, ncell, nint;
   auto load_meta = [&](uint32_t bb, uint32_t &c0_, int &ncell_, uint32_t &d0_, int &nb_, int &nint_,
@@ -239,10 +227,7 @@ apply_batches(const ApplyArgs<T> A, const Tables<T, n> tab) {
         if (cnt_next > 0) stage(cnt_next);
         return cnt_next > 0;
       };
-      if (WAVE)
-        cell_pipeline<dim, n, T, HN, WaveSync>(act, pa, pb, mask, any_mask, usrc, acc, Wc, Rc, cf, lm, Wl, tab, stage_next, A.dbg);
-      else
-        cell_pipeline<dim, n, T, HN, WgSync>(act, pa, pb, mask, any_mask, usrc, acc, Wc, Rc, cf, lm, Wl, tab, stage_next, A.dbg,
+      cell_pipeline<dim, n, T, HN, WgSync>(act, pa, pb, mask, any_mask, usrc, acc, Wc, Rc, cf, lm, Wl, tab, stage_next, A.dbg,
 #ifdef MFGPU_STAMPS
                                              (A.stamps && k == 1) ? A.stamps + (size_t)(A.batch_end + b) * 16 : nullptr
 #else
@@ -315,362 +300,6 @@ apply_batches(const ApplyArgs<T> A, const Tables<T, n> tab) {
   }  // batch loop
 }
 
-// Second pass of the two-pass mode: one thread per shared dof sums the partial sums the touching
-// batches left in the halo buffer, in ascending batch order (deterministic, no atomics).
-// Constrained rows are identity (laplace_operator_gpu.h:300-302).
-template <typename T>
-__global__ void __launch_bounds__(256)
-reduce_shared(T *__restrict__ dst, const T *__restrict__ src, const T *__restrict__ halo,
-              const uint32_t *__restrict__ sdofs, const uint32_t *__restrict__ s_off,
-              const uint32_t *__restrict__ s_idx, uint32_t ns, int add) {
-  const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= ns) return;
-  const uint32_t o = sdofs[i];
-  const uint32_t g = o & 0x7fffffffu;
-  T val;
-  if (o >> 31) {
-    val = src[g];
-  } else {
-    const uint32_t j0 = s_off[i], j1 = s_off[i + 1];
-    val = halo[s_idx[j0]];
-    for (uint32_t j = j0 + 1; j < j1; ++j) val += halo[s_idx[j]];
-  }
-  dst[g] = add ? dst[g] + val : val;
-}
-
-// Second pass, grouped form (mfgpu_plan.cpp): one wave per chunk of up to 64 consecutive dofs of one
-// toucher group.  The k partial sums of lane l are halo[gstarts[tstart + t] + offset + l]: k coalesced runs,
-// no per-partial index (the CSR form above reads one 32-bit slot index per partial and gathers).  Same
-// summation order (ascending batch), so both forms give bit-identical results.
-template <typename T>
-__global__ void __launch_bounds__(256)
-reduce_groups(T *__restrict__ dst, const T *__restrict__ src, const T *__restrict__ halo,
-              const uint32_t *__restrict__ sdofs, const uint4 *__restrict__ chunks,
-              const uint32_t *__restrict__ gstarts, uint32_t nchunks, int add) {
-  const uint32_t c = blockIdx.x * 4u + (threadIdx.x >> 6);
-  if (c >= nchunks) return;
-  const uint4 d = chunks[c];
-  const uint32_t lane = threadIdx.x & 63u, cnt = d.y & 0xffffu, k = d.y >> 16;
-  if (lane >= cnt) return;
-  const uint32_t o = sdofs[d.x + lane];
-  const uint32_t g = o & 0x7fffffffu;
-  T val;
-  if (o >> 31) {
-    val = src[g];
-  } else {
-    const uint32_t *gs = gstarts + d.z;
-    const uint32_t off = d.w + lane;
-    val = halo[gs[0] + off];
-    for (uint32_t t = 1; t < k; ++t) val += halo[gs[t] + off];
-  }
-  dst[g] = add ? dst[g] + val : val;
-}
-
-// =============================================================================================
-// Plane kernel (3D, n <= 5, no hanging nodes): a thread owns a 2D PLANE of the cell (n*n values in
-// registers), so two of the three contraction directions are register mat-vecs and a cell needs 3
-// LDS transposes instead of the pencil pipeline's 7 (about 66 instead of 145 LDS cycles per cell; the
-// pencil pipeline is LDS-throughput bound, profiles/r01_notes.md).  One wave = one workgroup = one
-// batch of up to CW = 64/n cells processed in ONE pass (n threads per cell):
-//   A (xy-plane, z = t): gather, S_x, S_y                         -> W
-//   B (xz-plane, y = t): S_z -> w;  r_B = D_z^T c D_z w + D_x^T c D_x w   -> W (w), R (r_B)
-//   A                  : r = r_B + D_y^T c D_y w;  S_y^T, S_x^T   -> W
-//   B                  : S_z^T, add into the batch accumulator
-// The batch arrays usrc / acc alias (every gather happens in the first stage).  The coefficient is read
-// straight from global memory in both layouts (25 contiguous doubles per thread in A, 5 runs of 5 in B).
-template <int n, int sgn, bool TRANS, int DIR, typename T>
-__device__ __forceinline__ void plane_mv(const T *__restrict__ M, const T (&in)[n * n], T (&out)[n * n]) {
-  // out[q along DIR] = sum_k m(q,k) in[k along DIR],  m(q,k) = TRANS ? M[k][q] : M[q][k]
-#pragma unroll
-  for (int o = 0; o < n; ++o)  // index of the other in-plane direction
-#pragma unroll
-    for (int q = 0; q < n; ++q) {
-      T t = T(0);
-#pragma unroll
-      for (int k = 0; k < n; ++k) {
-        const T m = TRANS ? tab_at<n, sgn>(M, k, q) : tab_at<n, sgn>(M, q, k);
-        const int idx = DIR == 0 ? k + n * o : o + n * k;
-        t = (k == 0) ? m * in[idx] : fma(m, in[idx], t);
-      }
-      out[DIR == 0 ? q + n * o : o + n * q] = t;
-    }
-}
-
-constexpr int kPlaneMaxDofs = 1088;  // 17 x 64: a batch's dof list / source values pass through registers
-
-template <int n, typename T, bool TWOPASS>
-__global__ void __launch_bounds__(64)
-apply_planes(const ApplyArgs<T> A, const Tables<T, n> tab) {
-  constexpr int nd = n * n * n, n2 = n * n;
-  constexpr int CW = 64 / n;  // cells per pass
-  constexpr int kGU = kPlaneMaxDofs / 64;
-  constexpr int PL = (CW * nd + 63) / 64;  // index-map items per lane
-  extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
-  T *buf = reinterpret_cast<T *>(smem_raw);  // usrc, then acc
-  T *Wb = buf + A.nb_max;
-  T *Rb = Wb + CW * nd;
-  uint16_t *Lb = reinterpret_cast<uint16_t *>(Rb + CW * nd);
-
-  const int lane = threadIdx.x;
-  const int lc = lane / n, t = lane - lc * n;
-  const uint32_t bend = A.batch_end;
-  uint32_t b = A.batch0 + blockIdx.x;
-  if (b >= bend) return;
-  T *Wc = Wb + lc * nd;
-  T *Rc = Rb + lc * nd;
-  const uint16_t *lm = Lb + lc * nd;
-
-  auto load_dofs = [&](uint32_t d0_, int nb_, uint32_t (&g_)[kGU]) {
-#pragma unroll
-    for (int j = 0; j < kGU; ++j) {
-      const int tt = lane + j * 64;
-      g_[j] = DBG(16) ? (uint32_t)tt : A.bdofs[d0_ + (tt < nb_ ? tt : nb_ - 1)];
-    }
-  };
-  auto load_src = [&](const uint32_t (&g_)[kGU], T (&sv_)[kGU]) {
-#pragma unroll
-    for (int j = 0; j < kGU; ++j) sv_[j] = DBG(2) ? T(1) : A.src[g_[j] & 0x7fffffffu];
-  };
-  uint32_t c0 = A.batch_cell_off[b], d0 = A.batch_dof_off[b];
-  int ncell = (int)(A.batch_cell_off[b + 1] - c0), nb = (int)(A.batch_dof_off[b + 1] - d0);
-  int nint = TWOPASS ? (int)A.batch_nint[b] : 0;
-  uint32_t hoff = TWOPASS ? A.halo_off[b] : 0u;
-  uint32_t G[kGU];
-  T SV[kGU];
-  uint16_t pl[PL];
-  T cB[n2], cA[n2];
-  auto load_lmap = [&](uint32_t c0_, int ncell_, uint16_t (&pl_)[PL]) {
-    const uint16_t *lg = A.lmap + (size_t)c0_ * nd;
-    const int cnt = ncell_ * nd;
-#pragma unroll
-    for (int j = 0; j < PL; ++j) {
-      const int i = lane + j * 64;
-      pl_[j] = DBG(8) ? (uint16_t)(i & 255) : lg[i < cnt ? i : cnt - 1];
-    }
-  };
-  auto load_coef = [&](uint32_t c0_, int ncell_) {
-    // coefficient planes of this thread's cell, straight from global memory in both layouts
-    const T *cf = A.coef + ((size_t)c0_ + (lc < ncell_ ? lc : 0)) * nd;
-#pragma unroll
-    for (int z = 0; z < n; ++z)
-#pragma unroll
-      for (int x = 0; x < n; ++x) cB[x + n * z] = DBG(8) ? T(1) : cf[x + n * t + n2 * z];
-#pragma unroll
-    for (int i = 0; i < n2; ++i) cA[i] = DBG(8) ? T(1) : cf[n2 * t + i];
-  };
-  load_dofs(d0, nb, G);
-  load_lmap(c0, ncell, pl);
-  load_src(G, SV);
-  load_coef(c0, ncell);
-
-  // Software pipeline over batches with the whole next batch in flight.  Issue points are chosen so
-  // that every use of a prefetched register finds only OLD loads outstanding (hipcc waits vmcnt(0)
-  // after the loop back-edge): at the top {next dof list, next index map}; after stage 3 {next source
-  // values, next coefficient planes -- into the registers stages 2 and 3 have just consumed}.
-  while (true) {
-    STAMP(0);
-    const bool act = lane < CW * n && lc < ncell;
-    STAMP(1);
-    // gathered source values -> LDS (constrained rows read as zero; the owning batch writes dst = src)
-#pragma unroll
-    for (int j = 0; j < kGU; ++j) {
-      const int tt = lane + j * 64;
-      const bool con = (G[j] >> 31) != 0;
-      if (tt < nb) {
-        buf[tt] = con ? T(0) : SV[j];
-        const bool owner = TWOPASS ? (tt < nint) : false;
-        if (con && owner) {
-          T *d = A.dst + (G[j] & 0x7fffffffu);
-          *d = A.add ? *d + SV[j] : SV[j];
-        }
-      }
-    }
-#pragma unroll
-    for (int j = 0; j < PL; ++j) {
-      const int i = lane + j * 64;
-      if (i < ncell * nd) Lb[i] = pl[j];
-    }
-    // next batch of this wave: dof list now, source values after the first stage
-    const uint32_t bn = b + gridDim.x;
-    const bool has_nb = bn < bend;
-    uint32_t c0n = c0, d0n = d0, hoffn = hoff;
-    int ncelln = ncell, nbn = nb, nintn = nint;
-    uint32_t Gn[kGU];
-    T SVn[kGU];
-    uint16_t pln[PL];
-    if (has_nb) {
-      c0n = A.batch_cell_off[bn];
-      ncelln = (int)(A.batch_cell_off[bn + 1] - c0n);
-      d0n = A.batch_dof_off[bn];
-      nbn = (int)(A.batch_dof_off[bn + 1] - d0n);
-      nintn = TWOPASS ? (int)A.batch_nint[bn] : 0;
-      hoffn = TWOPASS ? A.halo_off[bn] : 0u;
-      load_dofs(d0n, nbn, Gn);
-      load_lmap(c0n, ncelln, pln);
-    }
-    WaveSync::sync();
-    STAMP(2);  // gathered values + index map in LDS (waited for SV, pl)
-
-    T u[n2], v[n2];
-    // ---- stage 1, layout A (z = t): gather, S_x, S_y
-    if (act) {
-#pragma unroll
-      for (int i = 0; i < n2; ++i) u[i] = buf[lm[n2 * t + i]];
-      plane_mv<n, 1, true, 0>(tab.S, u, v);
-      plane_mv<n, 1, true, 1>(tab.S, v, u);
-#pragma unroll
-      for (int i = 0; i < n2; ++i) Wc[n2 * t + i] = u[i];
-    }
-    WaveSync::sync();
-    STAMP(3);  // stage 1 done
-    // every gather is done: the batch array becomes the accumulator
-#pragma unroll
-    for (int j = 0; j < kGU; ++j) {
-      const int tt = lane + j * 64;
-      if (tt < nb) buf[tt] = T(0);
-    }
-    // ---- stage 2, layout B (y = t): S_z; z- and x-derivative parts
-    T w[n2], r[n2];
-    if (act) {
-#pragma unroll
-      for (int z = 0; z < n; ++z)
-#pragma unroll
-        for (int x = 0; x < n; ++x) u[x + n * z] = Wc[x + n * t + n2 * z];
-      plane_mv<n, 1, true, 1>(tab.S, u, w);  // values at the quadrature points
-      plane_mv<n, -1, false, 1>(tab.Dt, w, u);
-#pragma unroll
-      for (int i = 0; i < n2; ++i) u[i] *= cB[i];
-      plane_mv<n, -1, true, 1>(tab.Dt, u, r);
-      plane_mv<n, -1, false, 0>(tab.Dt, w, u);
-#pragma unroll
-      for (int i = 0; i < n2; ++i) u[i] *= cB[i];
-      plane_mv<n, -1, true, 0>(tab.Dt, u, v);
-#pragma unroll
-      for (int z = 0; z < n; ++z)
-#pragma unroll
-        for (int x = 0; x < n; ++x) {
-          Wc[x + n * t + n2 * z] = w[x + n * z];
-          Rc[x + n * t + n2 * z] = r[x + n * z] + v[x + n * z];
-        }
-    }
-    WaveSync::sync();
-    STAMP(4);  // stage 2 done (waited for cB)
-    // ---- stage 3, layout A: y-derivative part, S_y^T, S_x^T
-    if (act) {
-#pragma unroll
-      for (int i = 0; i < n2; ++i) {
-        w[i] = Wc[n2 * t + i];
-        r[i] = Rc[n2 * t + i];
-      }
-      plane_mv<n, -1, false, 1>(tab.Dt, w, u);
-#pragma unroll
-      for (int i = 0; i < n2; ++i) u[i] *= cA[i];
-      plane_mv<n, -1, true, 1>(tab.Dt, u, v);
-#pragma unroll
-      for (int i = 0; i < n2; ++i) v[i] += r[i];
-      plane_mv<n, 1, false, 1>(tab.S, v, u);
-      plane_mv<n, 1, false, 0>(tab.S, u, v);
-#pragma unroll
-      for (int i = 0; i < n2; ++i) Wc[n2 * t + i] = v[i];
-    }
-    WaveSync::sync();
-    if (has_nb) {  // the rest of the next batch: source values, coefficient planes
-      load_src(Gn, SVn);
-      load_coef(c0n, ncelln);
-    }
-    STAMP(5);  // stage 3 done
-    // ---- stage 4, layout B: S_z^T, add into the batch accumulator
-    if (act) {
-#pragma unroll
-      for (int z = 0; z < n; ++z)
-#pragma unroll
-        for (int x = 0; x < n; ++x) u[x + n * z] = Wc[x + n * t + n2 * z];
-      plane_mv<n, 1, false, 1>(tab.S, u, v);
-#pragma unroll
-      for (int z = 0; z < n; ++z)
-#pragma unroll
-        for (int x = 0; x < n; ++x) lds_add(&buf[lm[x + n * t + n2 * z]], v[x + n * z]);
-    }
-    WaveSync::sync();
-    STAMP(6);  // stage 4 done
-    // ---- scatter: interior dofs -> dst, shared dofs -> halo slots (two-pass mode only)
-    {
-      T *halo = A.halo + hoff;
-      T old[kGU];
-      if (A.add) {
-#pragma unroll
-        for (int j = 0; j < kGU; ++j) old[j] = A.dst[G[j] & 0x7fffffffu];
-      }
-#pragma unroll
-      for (int j = 0; j < kGU; ++j) {
-        const int tt = lane + j * 64;
-        if (DBG(4)) {
-          asm volatile("" ::"v"(buf[tt < nb ? tt : 0]));
-        } else if (tt < nint) {
-          if (!(G[j] >> 31)) A.dst[G[j]] = A.add ? old[j] + buf[tt] : buf[tt];
-        } else if (tt < nb) {
-          halo[tt - nint] = buf[tt];
-        }
-      }
-    }
-    STAMP(7);  // scatter issued
-    if (!has_nb) break;
-    WaveSync::sync();  // buf / Lb are rewritten for the next batch
-    b = bn;
-    c0 = c0n;
-    ncell = ncelln;
-    d0 = d0n;
-    nb = nbn;
-    nint = nintn;
-    hoff = hoffn;
-#pragma unroll
-    for (int j = 0; j < kGU; ++j) {
-      G[j] = Gn[j];
-      SV[j] = SVn[j];
-    }
-#pragma unroll
-    for (int j = 0; j < PL; ++j) pl[j] = pln[j];
-  }
-}
-
-template <int n, typename T>
-static size_t plane_lds_bytes(uint32_t nb_max) {
-  constexpr int nd = n * n * n, CW = 64 / n;
-  return (size_t)(nb_max + 2 * CW * nd) * sizeof(T) + (size_t)CW * nd * sizeof(uint16_t);
-}
-
-template <typename T>
-hipError_t plane_launch(int n, const ApplyArgs<T> &a, const double *S, const double *Dt, uint32_t grid,
-                        hipStream_t st, bool configure_only, size_t *lds_out, int *occupancy) {
-#define PLANE_CASE(N)                                                                                       \
-  case N: {                                                                                                 \
-    const size_t lds = plane_lds_bytes<N, T>(a.nb_max);                                                     \
-    if (lds_out) *lds_out = lds;                                                                            \
-    if (configure_only) {                                                                                   \
-      hipError_t e = hipFuncSetAttribute((const void *)apply_planes<N, T, true>,                            \
-                                         hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);            \
-      if (e == hipSuccess && occupancy)                                                                     \
-        e = hipOccupancyMaxActiveBlocksPerMultiprocessor(occupancy, apply_planes<N, T, true>, 64, lds);     \
-      return e;                                                                                             \
-    }                                                                                                       \
-    Tables<T, N> tab;                                                                                       \
-    for (int i = 0; i < ((N + 1) / 2) * N; ++i) {                                                           \
-      tab.S[i] = (T)S[i];                                                                                   \
-      tab.Dt[i] = (T)Dt[i];                                                                                 \
-    }                                                                                                       \
-    hipLaunchKernelGGL((apply_planes<N, T, true>), dim3(grid), dim3(64), lds, st, a, tab);                  \
-    return hipGetLastError();                                                                               \
-  }
-  switch (n) {
-    PLANE_CASE(2)
-    PLANE_CASE(3)
-    PLANE_CASE(4)
-    PLANE_CASE(5)
-    default: return hipErrorInvalidValue;
-  }
-#undef PLANE_CASE
-}
-
 // dofs no cell touches (e.g. hanging nodes eliminated from loc2glob): vmult gives
 // dst = src on constrained rows (identity, laplace_operator_gpu.h:300-302) and 0 elsewhere.
 template <typename T>
@@ -723,50 +352,45 @@ __global__ void fill_kernel(T *v, size_t n, T a) {
 // ---------------------------------------------------------------------------------------------
 
 template <int dim, int n, typename T>
-static size_t lds_bytes_t(uint32_t nb_max, bool wave) {
+static size_t lds_bytes_t(uint32_t nb_max) {
   constexpr int nd = (dim == 3) ? n * n * n : n * n;
-  const int NG = 1;
-  const int CH = (wave ? 64 : 256) / (nd / n);
-  return (size_t)nb_max * sizeof(double) + (size_t)(nb_max + NG * 3 * CH * nd + n * n) * sizeof(T) +
-         (size_t)NG * CH * nd * sizeof(uint16_t);
+  const int CH = 256 / (nd / n);
+  return (size_t)nb_max * sizeof(double) + (size_t)(nb_max + 3 * CH * nd + n * n) * sizeof(T) +
+         (size_t)CH * nd * sizeof(uint16_t);
 }
 
-template <int dim, int n, typename T, bool HN, bool TP, bool WV>
+template <int dim, int n, typename T, bool HN, bool TP>
 static hipError_t launch_k(const ApplyArgs<T> &a, const Tables<T, n> &tab, size_t lds, uint32_t grid, hipStream_t st) {
-  hipLaunchKernelGGL((apply_batches<dim, n, T, HN, TP, WV>), dim3(grid), dim3(WV ? 64 : 256), lds, st, a, tab);
+  hipLaunchKernelGGL((apply_batches<dim, n, T, HN, TP>), dim3(grid), dim3(256), lds, st, a, tab);
   return hipGetLastError();
 }
 
-// dispatch over the run-time switches (hanging nodes, scatter mode, workgroup size)
-#define MFGPU_SWITCH(FN, ...)                                                       \
-  (wave ? (hn ? (twopass ? FN<dim, n, T, true, true, true>(__VA_ARGS__)              \
-                         : FN<dim, n, T, true, false, true>(__VA_ARGS__))            \
-              : (twopass ? FN<dim, n, T, false, true, true>(__VA_ARGS__)             \
-                         : FN<dim, n, T, false, false, true>(__VA_ARGS__)))          \
-        : (hn ? (twopass ? FN<dim, n, T, true, true, false>(__VA_ARGS__)             \
-                         : FN<dim, n, T, true, false, false>(__VA_ARGS__))           \
-              : (twopass ? FN<dim, n, T, false, true, false>(__VA_ARGS__)            \
-                         : FN<dim, n, T, false, false, false>(__VA_ARGS__))))
+// dispatch over the run-time switches (hanging nodes, scatter mode)
+#define MFGPU_SWITCH(FN, ...)                                             \
+  (hn ? (twopass ? FN<dim, n, T, true, true>(__VA_ARGS__)                  \
+                 : FN<dim, n, T, true, false>(__VA_ARGS__))                \
+      : (twopass ? FN<dim, n, T, false, true>(__VA_ARGS__)                 \
+                 : FN<dim, n, T, false, false>(__VA_ARGS__)))
 
 template <int dim, int n, typename T>
 static hipError_t launch_t(const ApplyArgs<T> &a, const double *S, const double *Dt, bool hn,
-                           bool twopass, bool wave, uint32_t grid, hipStream_t st) {
+                           bool twopass, uint32_t grid, hipStream_t st) {
   Tables<T, n> tab;
   for (int i = 0; i < ((n + 1) / 2) * n; ++i) {
     tab.S[i] = (T)S[i];
     tab.Dt[i] = (T)Dt[i];
   }
-  const size_t lds = lds_bytes_t<dim, n, T>(a.nb_max, wave);
+  const size_t lds = lds_bytes_t<dim, n, T>(a.nb_max);
   return MFGPU_SWITCH(launch_k, a, tab, lds, grid, st);
 }
 
-template <int dim, int n, typename T, bool HN, bool TP, bool WV>
+template <int dim, int n, typename T, bool HN, bool TP>
 static hipError_t configure_k(size_t lds) {
-  return hipFuncSetAttribute((const void *)apply_batches<dim, n, T, HN, TP, WV>,
+  return hipFuncSetAttribute((const void *)apply_batches<dim, n, T, HN, TP>,
                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
 }
 template <int dim, int n, typename T>
-static hipError_t configure_t(size_t lds, bool wave) {
+static hipError_t configure_t(size_t lds) {
   hipError_t e = hipSuccess;
   for (int hn_ = 0; hn_ < 2 && e == hipSuccess; ++hn_)
     for (int tp_ = 0; tp_ < 2 && e == hipSuccess; ++tp_) {
@@ -776,12 +400,12 @@ static hipError_t configure_t(size_t lds, bool wave) {
   return e;
 }
 
-template <int dim, int n, typename T, bool HN, bool TP, bool WV>
+template <int dim, int n, typename T, bool HN, bool TP>
 static hipError_t occupancy_k(size_t lds, int *blocks) {
-  return hipOccupancyMaxActiveBlocksPerMultiprocessor(blocks, apply_batches<dim, n, T, HN, TP, WV>, WV ? 64 : 256, lds);
+  return hipOccupancyMaxActiveBlocksPerMultiprocessor(blocks, apply_batches<dim, n, T, HN, TP>, 256, lds);
 }
 template <int dim, int n, typename T>
-static hipError_t occupancy_t(bool hn, bool twopass, bool wave, size_t lds, int *blocks) {
+static hipError_t occupancy_t(bool hn, bool twopass, size_t lds, int *blocks) {
   return MFGPU_SWITCH(occupancy_k, lds, blocks);
 }
 
@@ -803,8 +427,8 @@ static hipError_t occupancy_t(bool hn, bool twopass, bool wave, size_t lds, int 
   }
 
 template <typename T>
-size_t apply_lds_bytes(int dim, int n, uint32_t nb_max, bool wave) {
-#define CALL(D, N) lds_bytes_t<D, N, T>(nb_max, wave)
+size_t apply_lds_bytes(int dim, int n, uint32_t nb_max) {
+#define CALL(D, N) lds_bytes_t<D, N, T>(nb_max)
   switch (dim * 10 + n) {
     case 22: return CALL(2, 2);
     case 23: return CALL(2, 3);
@@ -824,43 +448,25 @@ size_t apply_lds_bytes(int dim, int n, uint32_t nb_max, bool wave) {
 }
 
 template <typename T>
-hipError_t apply_configure(int dim, int n, size_t lds, bool wave) {
-#define CALL(D, N) configure_t<D, N, T>(lds, wave)
+hipError_t apply_configure(int dim, int n, size_t lds) {
+#define CALL(D, N) configure_t<D, N, T>(lds)
   MFGPU_DISPATCH(CALL)
 #undef CALL
 }
 
 template <typename T>
-hipError_t apply_occupancy(int dim, int n, bool hn, bool twopass, bool wave, size_t lds, int *blocks) {
-#define CALL(D, N) occupancy_t<D, N, T>(hn, twopass, wave, lds, blocks)
+hipError_t apply_occupancy(int dim, int n, bool hn, bool twopass, size_t lds, int *blocks) {
+#define CALL(D, N) occupancy_t<D, N, T>(hn, twopass, lds, blocks)
   MFGPU_DISPATCH(CALL)
 #undef CALL
 }
 
 template <typename T>
 hipError_t apply_launch(int dim, int n, const ApplyArgs<T> &a, const double *S, const double *Dt,
-                        bool hn, bool twopass, bool wave, uint32_t grid, hipStream_t st) {
-#define CALL(D, N) launch_t<D, N, T>(a, S, Dt, hn, twopass, wave, grid, st)
+                        bool hn, bool twopass, uint32_t grid, hipStream_t st) {
+#define CALL(D, N) launch_t<D, N, T>(a, S, Dt, hn, twopass, grid, st)
   MFGPU_DISPATCH(CALL)
 #undef CALL
-}
-
-template <typename T>
-hipError_t reduce_launch(T *dst, const T *src, const T *halo, const uint32_t *sdofs, const uint32_t *s_off,
-                         const uint32_t *s_idx, uint32_t ns, int add, hipStream_t st) {
-  if (ns == 0) return hipSuccess;
-  hipLaunchKernelGGL(reduce_shared<T>, dim3((ns + 255) / 256), dim3(256), 0, st, dst, src, halo, sdofs,
-                     s_off, s_idx, ns, add);
-  return hipGetLastError();
-}
-
-template <typename T>
-hipError_t reduce_groups_launch(T *dst, const T *src, const T *halo, const uint32_t *sdofs, const uint32_t *chunks,
-                                const uint32_t *gstarts, uint32_t nchunks, int add, hipStream_t st) {
-  if (nchunks == 0) return hipSuccess;
-  hipLaunchKernelGGL(reduce_groups<T>, dim3((nchunks + 3) / 4), dim3(256), 0, st, dst, src, halo, sdofs,
-                     reinterpret_cast<const uint4 *>(chunks), gstarts, nchunks, add);
-  return hipGetLastError();
 }
 
 template <typename T>
@@ -900,17 +506,11 @@ hipError_t fill_launch(T *v, size_t n, T a, hipStream_t st) {
 }
 
 #define INST(T)                                                                                         \
-  template hipError_t plane_launch<T>(int, const ApplyArgs<T> &, const double *, const double *, uint32_t, \
-                                      hipStream_t, bool, size_t *, int *);                              \
-  template size_t apply_lds_bytes<T>(int, int, uint32_t, bool);                                         \
-  template hipError_t apply_configure<T>(int, int, size_t, bool);                                       \
-  template hipError_t apply_occupancy<T>(int, int, bool, bool, bool, size_t, int *);                    \
+  template size_t apply_lds_bytes<T>(int, int, uint32_t);                                               \
+  template hipError_t apply_configure<T>(int, int, size_t);                                             \
+  template hipError_t apply_occupancy<T>(int, int, bool, bool, size_t, int *);                          \
   template hipError_t apply_launch<T>(int, int, const ApplyArgs<T> &, const double *, const double *,   \
-                                      bool, bool, bool, uint32_t, hipStream_t);                         \
-  template hipError_t reduce_launch<T>(T *, const T *, const T *, const uint32_t *, const uint32_t *,   \
-                                       const uint32_t *, uint32_t, int, hipStream_t);                   \
-  template hipError_t reduce_groups_launch<T>(T *, const T *, const T *, const uint32_t *, const uint32_t *, \
-                                              const uint32_t *, uint32_t, int, hipStream_t);            \
+                                      bool, bool, uint32_t, hipStream_t);                               \
   template hipError_t orphan_launch<T>(T *, const T *, const uint32_t *, uint32_t, int, hipStream_t);   \
   template hipError_t coefficient_launch<T>(T *, const T *, size_t, int, hipStream_t);                  \
   template hipError_t fold_launch<T>(T *, const T *, const T *, const T *, const uint32_t *, uint32_t,  \

@@ -17,7 +17,7 @@
 // coefficient on the Cartesian path.
 #include <hip/hip_runtime.h>
 
-#include "mfgpu_cell.cuh"
+#include "mfgpu_cell.h"
 #include "mfgpu_kernels.h"
 
 namespace mfgpu {

@@ -27,7 +27,7 @@
 // gather / scatter: fee_gpu.cuh:323-363; constrained rows: constraint_handler_gpu.cu:247-289.
 #include <hip/hip_runtime.h>
 
-#include "mfgpu_cell.cuh"
+#include "mfgpu_cell.h"
 #include "mfgpu_kernels.h"
 
 namespace mfgpu {
@@ -298,21 +298,35 @@ apply_planes3(const ApplyArgs<T> A, const TablesEO<T, n> tab) {
     auto hookA = [&](int s) {  // 2 n steps: the gather of the next batch
       MFGPU_PIN_VMEM();
 #pragma unroll
-      for (int j = (KGU * s) / (2 * n); j < (KGU * (s + 1)) / (2 * n); ++j) SVn[j] = src_at(Gn[j]);
+      for (int j = (KGU * s) / (2 * n); j < (KGU * (s + 1)) / (2 * n); ++j)
+#if defined(MFGPU_ABL) && (MFGPU_ABL & 1)  // ablation builds (tools/ablate_p.sh), never the product
+        SVn[j] = (T)Gn[j];
+#else
+        SVn[j] = src_at(Gn[j]);
+#endif
       MFGPU_PIN_VMEM();
     };
     auto hookB = [&](int s) {  // 5 n steps: the previous batch's scatter
       MFGPU_PIN_VMEM();
 #pragma unroll
       for (int j = (KGU * s) / (5 * n); j < (KGU * (s + 1)) / (5 * n); ++j)
+#if defined(MFGPU_ABL) && (MFGPU_ABL & 2)
+        asm volatile("" ::"v"(R[j]), "v"(Gp[j]));
+#else
         scatter_slot(j, bp, Gp[j], R[j], old[j]);
+#endif
       MFGPU_PIN_VMEM();
     };
     const T *const cnext = A.coefp + (size_t)b1 * (n2 * NT) + tk;
     auto hookC = [&](int s) {  // 2 n steps: the next batch's coefficient rows (stage B is done with this batch's)
       MFGPU_PIN_VMEM();
 #pragma unroll
-      for (int r = (n2 * s) / (2 * n); r < (n2 * (s + 1)) / (2 * n); ++r) Cc[r] = nt_load(cnext + r * NT);
+      for (int r = (n2 * s) / (2 * n); r < (n2 * (s + 1)) / (2 * n); ++r)
+#if defined(MFGPU_ABL) && (MFGPU_ABL & 4)
+        asm volatile("" : "+v"(Cc[r]) : "v"(cnext));
+#else
+        Cc[r] = nt_load(cnext + r * NT);
+#endif
       MFGPU_PIN_VMEM();
     };
 

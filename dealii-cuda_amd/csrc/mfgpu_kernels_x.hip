@@ -18,7 +18,7 @@
 //   w = S_z S_y S_x u,   r = sum_d D_d^T (c .* D_d w),   out = S_x^T S_z^T S_y^T r
 #include <hip/hip_runtime.h>
 
-#include "mfgpu_cell.cuh"
+#include "mfgpu_cell.h"
 #include "mfgpu_kernels.h"
 
 namespace mfgpu {

@@ -56,28 +56,46 @@ def test_vmult_matches_oracle(dim, p, n, nt, colored):
     assert rel(y, o.vmult(od, x.astype(mf.np_dtype(nt)).astype(np.float64))) <= TOL[nt]
 
 
-KNOBS = [("MFGPU_X", "0", "apply_batches"), ("MFGPU_GROUPS", "0", "apply_batches_x"),
-         ("MFGPU_GRID", "13", "apply_batches_x"),  # persistent grid that is no multiple of the 8 XCDs
-         ("MFGPU_NOPERM", "1", "apply_batches_x"),  # natural lane -> pencil ownership in the y- and z-stages
-         ("MFGPU_LS", "1", "apply_batches_ls"),
-         ("MFGPU_WAVE", "1", "apply_batches"), ("MFGPU_PLANE", "1", "apply_planes")]
+KERNELS = [(mf.KERNEL_PENCILS, "apply_batches"), (mf.KERNEL_PENCILS_X, "apply_batches_x"),
+           (mf.KERNEL_PLANES, "apply_planes3")]
 
 
-@pytest.mark.parametrize("knob,value,kernel", KNOBS, ids=[k[0] + "=" + k[1] for k in KNOBS])
-@pytest.mark.parametrize("dim,p,n", [(3, 4, 7), (3, 2, 9), (2, 3, 12)])
-def test_kernel_variants_match_oracle(knob, value, kernel, dim, p, n, monkeypatch):
-    """The non-default kernel variants (environment knobs read by mfgpu_create; tuning experiments,
-    profiles/r01_notes.md) compute the same operator: vmult and vmult_add against the oracle."""
-    monkeypatch.setenv(knob, value)
-    mesh = mf.Mesh.uniform(dim, p, n)
+@pytest.mark.parametrize("kern,name", KERNELS, ids=[k[1] for k in KERNELS])
+@pytest.mark.parametrize("p,n", [(4, 7), (2, 9), (3, 6)])
+@pytest.mark.parametrize("nt", [mf.F64, mf.F32])
+def test_kernel_families_match_oracle(kern, name, p, n, nt):
+    """every cell-loop kernel family that covers a 3D conforming mesh (mfgpu_desc.kernel) computes the same
+    operator: vmult and vmult_add against the oracle"""
+    mesh = mf.Mesh.uniform(3, p, n, number_type=nt)
     od = oracle_desc_from_mesh(mesh, dtype=np.float64)
+    mesh.desc.kernel = kern
     op = mf.Operator(mesh.desc, mesh)
-    if dim == 3 and knob != "MFGPU_LS":
-        assert op.kernel_name() == kernel  # (MFGPU_GROUPS=0: per-dof CSR form of pass 2 instead of the grouped one)
+    assert op.kernel_name() == name
     rng = np.random.default_rng(17)
     x, y0 = rng.standard_normal(mesh.n_dofs), rng.standard_normal(mesh.n_dofs)
-    assert rel(gpu_vmult(op, x), o.vmult(od, x)) <= 1e-12
-    assert rel(gpu_vmult(op, x, y0=y0), o.vmult_add(od, y0, x)) <= 1e-12
+    xt, y0t = (v.astype(mf.np_dtype(nt)).astype(np.float64) for v in (x, y0))
+    assert rel(gpu_vmult(op, x, nt), o.vmult(od, xt)) <= TOL[nt]
+    assert rel(gpu_vmult(op, x, nt, y0=y0), o.vmult_add(od, y0t, xt)) <= TOL[nt]
+
+
+# batches of several chunks of cells (the production default on large meshes; small meshes default to one cell per
+# batch): degree-dependent lane masks, idle lanes and chunk-boundary clamps of the pencil kernels
+@pytest.mark.parametrize("p,n,cells", [(1, 12, 256), (2, 10, 256), (3, 8, 256), (4, 6, 27), (5, 4, 256), (6, 3, 256)])
+@pytest.mark.parametrize("kern", [mf.KERNEL_PENCILS, mf.KERNEL_PENCILS_X], ids=["apply_batches", "apply_batches_x"])
+@pytest.mark.parametrize("nt", [mf.F64, mf.F32])
+def test_pencil_kernels_multi_chunk_batches(p, n, cells, kern, nt):
+    mesh = mf.Mesh.uniform(3, p, n, number_type=nt)
+    od = oracle_desc_from_mesh(mesh, dtype=np.float64)
+    mesh.desc.kernel = kern
+    mesh.desc.max_cells_per_batch = cells
+    op = mf.Operator(mesh.desc, mesh)
+    st = op.plan_stats()
+    assert st["n_batches"] >= 2 and st["max_batch_cells"] > 256 // (p + 1) ** 2, st  # more than one chunk
+    rng = np.random.default_rng(p * 31 + n)
+    x, y0 = rng.standard_normal(mesh.n_dofs), rng.standard_normal(mesh.n_dofs)
+    xt, y0t = (v.astype(mf.np_dtype(nt)).astype(np.float64) for v in (x, y0))
+    assert rel(gpu_vmult(op, x, nt), o.vmult(od, xt)) <= TOL[nt]
+    assert rel(gpu_vmult(op, x, nt, y0=y0), o.vmult_add(od, y0t, xt)) <= TOL[nt]
 
 
 @pytest.mark.parametrize("colored", [False, True])
@@ -167,7 +185,7 @@ def test_errors_are_loud():
     with pytest.raises(mf.MfgpuError, match="alias"):
         op.vmult(v, v)
     d2 = mf.Desc.from_buffer_copy(mesh.desc)
-    d2.flags = 0  # general-Jacobian path is not implemented: must refuse, not fall back
+    d2.flags = 0  # the general-Jacobian path covers 3D only: a 2D description must be refused, not fall back
     with pytest.raises(mf.MfgpuError, match="UNIFORM_J0"):
         mf.Operator(d2, mesh)
 
@@ -237,15 +255,17 @@ def _all_masks(dim):
 
 @pytest.mark.parametrize("dim,p,n", [(2, 1, 8), (2, 2, 8), (2, 4, 8), (3, 1, 5), (3, 2, 4), (3, 3, 4), (3, 4, 4), (3, 5, 3)])
 @pytest.mark.parametrize("colored", [False, True, "x"])
-def test_hanging_node_stages_synthetic_masks(dim, p, n, colored, monkeypatch):
+def test_hanging_node_stages_synthetic_masks(dim, p, n, colored):
     """in-kernel resolve_hanging_nodes (NOTRANSPOSE before evaluate, TRANSPOSE after integrate,
     fee_gpu.cuh:333-335,349-351) against the oracle's emulation for every mask type.  The masks are
     assigned to cells of a conforming mesh: algebraically A = sum_cells P^T C^T K C P either way."""
     if colored == "x":  # two-pass mode with apply_batches instead of the 3D default apply_batches_x
         if dim != 3:
             pytest.skip("apply_batches_x is a 3D kernel: 2D always runs apply_batches")
-        monkeypatch.setenv("MFGPU_X", "0")
         colored = False
+        kernel = mf.KERNEL_PENCILS
+    else:
+        kernel = mf.KERNEL_AUTO
     od = o.uniform_mesh_desc(dim, p, n)
     masks = _all_masks(dim)
     rng = np.random.default_rng(5)
@@ -255,7 +275,7 @@ def test_hanging_node_stages_synthetic_masks(dim, p, n, colored, monkeypatch):
     od.constraint_mask = cm
     x = rng.standard_normal(od.n_dofs)
     ref = o.vmult(od, x)
-    desc, keep = desc_from_oracle(od, colored=colored)
+    desc, keep = desc_from_oracle(od, colored=colored, kernel=kernel)
     op = mf.Operator(desc, keep)
     assert rel(gpu_vmult(op, x), ref) <= 1e-12
     # and the assembled C^T K C form
@@ -282,15 +302,15 @@ def test_adaptive_mesh_with_hanging_nodes(dim, p, nref, colored):
 
 
 @pytest.mark.parametrize("p,nref", [(4, 4), (2, 4), (3, 5)])
-@pytest.mark.parametrize("xk", ["1", "0"])
-def test_adaptive_mesh_both_cell_loop_kernels(p, nref, xk, monkeypatch):
-    """apply_batches_x is the 3D two-pass default with and without hanging nodes; MFGPU_X=0 selects
+@pytest.mark.parametrize("xk", [True, False])
+def test_adaptive_mesh_both_cell_loop_kernels(p, nref, xk):
+    """apply_batches_x is the 3D two-pass default on meshes with hanging nodes; mfgpu_desc.kernel = PENCILS selects
     apply_batches (which also serves 2D and the coloured mode): same operator on an adaptive mesh."""
-    monkeypatch.setenv("MFGPU_X", xk)
     mesh = mf.Mesh.adaptive(3, p, nref)
     od = oracle_desc_from_mesh(mesh, dtype=np.float64)
+    mesh.desc.kernel = mf.KERNEL_AUTO if xk else mf.KERNEL_PENCILS
     op = mf.Operator(mesh.desc, mesh)
-    assert op.kernel_name() == ("apply_batches_x" if xk == "1" else "apply_batches")
+    assert op.kernel_name() == ("apply_batches_x" if xk else "apply_batches")
     rng = np.random.default_rng(5)
     x, y0 = rng.standard_normal(mesh.n_dofs), rng.standard_normal(mesh.n_dofs)
     assert rel(gpu_vmult(op, x), o.vmult(od, x)) <= 1e-12
