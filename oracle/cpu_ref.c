@@ -8,7 +8,10 @@
  *   constrained-row handling of vmult_add (laplace_operator_gpu.h:286-303), dst = 0 first (:221).
  * It stands in for bmop-cpu.cc / laplace_operator_cpu.cc:122-211, whose arithmetic lives in an
  * external deal.II that is not available: threads over cells of one colour (the reference uses
- * deal.II's TBB partition_color scheme, laplace_operator_cpu.cc:51-52), no explicit SIMD.
+ * deal.II's TBB partition_color scheme, laplace_operator_cpu.cc:51-52) and, in 3D, SIMD over VL = 8 cells
+ * (the reference's VectorizedArray<number> over cells, laplace_operator_cpu.cc:122-143): structure-of-arrays
+ * cell data [dof][8 cells], compile-time n, the lane loops vectorised by the compiler (AVX-512 on the GPU
+ * box's host); one parallel region per vmult.  The arithmetic per cell is the scalar path's, in the same order.
  * PARITY UNPINNED beyond the reference's two test procedures (see mf_oracle.py header); this file is
  * checked against mf_oracle.py in tests/test_cpu_ref.py.
  */
@@ -65,6 +68,93 @@ static void cell_apply(int dim, int n, const double *Se, const double *Ge, const
   }
 }
 
+/* ---- 3D, VL cells at a time (SIMD over cells) ------------------------------------------------------------ */
+#define VL 8
+#define INL static inline __attribute__((always_inline))
+
+/* out[i][l] = sum_k M[q*n+k] in[base + k*s][l] along direction d; n is a compile-time constant at every call */
+INL void contract_v(const int n, const int d, const double *restrict M, const double *restrict in,
+                    double *restrict out) {
+  const int nd = n * n * n, s = d == 0 ? 1 : d == 1 ? n : n * n;
+  for (int i = 0; i < nd; ++i) {
+    const int q = (i / s) % n;
+    const int base = i - q * s;
+    double t[VL];
+#pragma omp simd
+    for (int l = 0; l < VL; ++l) t[l] = 0.0;
+    for (int k = 0; k < n; ++k) {
+      const double m = M[q * n + k];
+      const double *restrict x = in + (size_t)(base + k * s) * VL;
+#pragma omp simd
+      for (int l = 0; l < VL; ++l) t[l] += m * x[l];
+    }
+#pragma omp simd
+    for (int l = 0; l < VL; ++l) out[(size_t)i * VL + l] = t[l];
+  }
+}
+
+/* cells k0 .. k0+cnt-1 (cnt <= VL) of the colour-sorted cell list; lanes >= cnt repeat the last cell and are not scattered */
+INL void cells_apply_v(const int n, const double *Se, const double *Ge, const double *S, const double *G,
+                       const uint32_t *l2g, const double *coef, const double *jxw, const double *j0,
+                       const uint32_t *cell_order, int64_t k0, int cnt, double *dst, const double *src) {
+  const int nd = n * n * n;
+  double u[MAXND * VL], g[3][MAXND * VL], t1[MAXND * VL], t2[MAXND * VL], c[MAXND * VL];
+  uint32_t cell[VL];
+  for (int l = 0; l < VL; ++l) cell[l] = cell_order[k0 + (l < cnt ? l : cnt - 1)];
+  for (int l = 0; l < VL; ++l) {
+    const uint32_t *idx = l2g + (size_t)cell[l] * nd;
+    const double *cf = coef + (size_t)cell[l] * nd, *jw = jxw + (size_t)cell[l] * nd;
+    const double jj = j0[cell[l]];
+    for (int i = 0; i < nd; ++i) {
+      u[(size_t)i * VL + l] = src[idx[i]];
+      c[(size_t)i * VL + l] = cf[i];
+      t1[(size_t)i * VL + l] = jw[i]; /* staged: JxW */
+    }
+    for (int i = 0; i < nd; ++i) t2[(size_t)i * VL + l] = jj; /* staged: J0 */
+  }
+  /* evaluate: reduce along x, then y, then z; quadrature-point operation ((coef * (J0 * g)) * J0) * JxW */
+  double jwv[MAXND * VL], j0v[MAXND * VL];
+  memcpy(jwv, t1, sizeof(double) * nd * VL);
+  memcpy(j0v, t2, sizeof(double) * nd * VL);
+  for (int d = 0; d < 3; ++d) {
+    contract_v(n, 0, d == 0 ? Ge : Se, u, t1);
+    contract_v(n, 1, d == 1 ? Ge : Se, t1, t2);
+    contract_v(n, 2, d == 2 ? Ge : Se, t2, g[d]);
+    for (int i = 0; i < nd * VL; ++i) g[d][i] = ((c[i] * (j0v[i] * g[d][i])) * j0v[i]) * jwv[i];
+  }
+  /* integrate */
+  double out[MAXND * VL];
+  for (int i = 0; i < nd * VL; ++i) out[i] = 0.0;
+  for (int d = 0; d < 3; ++d) {
+    contract_v(n, 0, d == 0 ? G : S, g[d], t1);
+    contract_v(n, 1, d == 1 ? G : S, t1, t2);
+    contract_v(n, 2, d == 2 ? G : S, t2, t1);
+    for (int i = 0; i < nd * VL; ++i) out[i] += t1[i];
+  }
+  for (int l = 0; l < cnt; ++l) {
+    const uint32_t *idx = l2g + (size_t)cell[l] * nd;
+    for (int i = 0; i < nd; ++i) dst[idx[i]] += out[(size_t)i * VL + l];
+  }
+}
+
+#define DEF_COLOUR_LOOP(N)                                                                                    \
+  static void colour_loop_##N(const double *Se, const double *Ge, const double *S, const double *G,             \
+                              const uint32_t *l2g, const double *coef, const double *jxw, const double *j0,   \
+                              const uint32_t *cell_order, int64_t kb, int64_t ke, double *dst, const double *src) { \
+    const int64_t nblk = (ke - kb + VL - 1) / VL;                                                               \
+    _Pragma("omp for schedule(static)") for (int64_t blk = 0; blk < nblk; ++blk) {                              \
+      const int64_t k0 = kb + blk * VL;                                                                         \
+      const int cnt = (int)(ke - k0 < VL ? ke - k0 : VL);                                                       \
+      cells_apply_v(N, Se, Ge, S, G, l2g, coef, jxw, j0, cell_order, k0, cnt, dst, src);                        \
+    }                                                                                                           \
+  }
+DEF_COLOUR_LOOP(2)
+DEF_COLOUR_LOOP(3)
+DEF_COLOUR_LOOP(4)
+DEF_COLOUR_LOOP(5)
+DEF_COLOUR_LOOP(6)
+DEF_COLOUR_LOOP(7)
+
 /* dst = A src.  Cells are visited colour by colour (color_off[ncolors+1] into cell_order); cells of
  * one colour share no dof.  src is modified and restored like the reference does. Returns threads. */
 int cpu_ref_vmult(int dim, int n, uint32_t n_dofs, const uint32_t *l2g, const double *coef,
@@ -96,6 +186,18 @@ int cpu_ref_vmult(int dim, int n, uint32_t n_dofs, const uint32_t *l2g, const do
       src[constrained[i]] = 0.0;
     }
     for (int c = 0; c < ncolors; ++c) {
+      if (dim == 3) { /* SIMD over 8 cells (cells of one colour share no dof, so the lanes' scatters are independent) */
+        const int64_t kb = color_off[c], ke = color_off[c + 1];
+        switch (n) {
+          case 2: colour_loop_2(Se, Ge, sv, sg, l2g, coef, jxw, j0, cell_order, kb, ke, dst, src); break;
+          case 3: colour_loop_3(Se, Ge, sv, sg, l2g, coef, jxw, j0, cell_order, kb, ke, dst, src); break;
+          case 4: colour_loop_4(Se, Ge, sv, sg, l2g, coef, jxw, j0, cell_order, kb, ke, dst, src); break;
+          case 5: colour_loop_5(Se, Ge, sv, sg, l2g, coef, jxw, j0, cell_order, kb, ke, dst, src); break;
+          case 6: colour_loop_6(Se, Ge, sv, sg, l2g, coef, jxw, j0, cell_order, kb, ke, dst, src); break;
+          default: colour_loop_7(Se, Ge, sv, sg, l2g, coef, jxw, j0, cell_order, kb, ke, dst, src); break;
+        }
+        continue;
+      }
 #pragma omp for schedule(static)
       for (int64_t k = color_off[c]; k < (int64_t)color_off[c + 1]; ++k) {
         const uint32_t cell = cell_order[k];

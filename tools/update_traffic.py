@@ -1,6 +1,10 @@
 #!/usr/bin/env python3
 """profiles/traffic_latest.json (read by bench.py for roofline.traffic) from a tools/profile_bench.sh
-traffic summary.  usage: tools/update_traffic.py SUMMARY_traffic.json WORKLOAD KERNEL_SUBSTRING"""
+traffic summary.  usage: tools/update_traffic.py SUMMARY_traffic.json WORKLOAD KERNEL_SUBSTRING
+The entry records the hash of the library sources it was measured on (bench.py's csrc_sha16): bench.py reports the
+figure only while the sources are unchanged."""
+import glob
+import hashlib
 import json
 import os
 import sys
@@ -12,9 +16,14 @@ v = t["kernels"][name]
 out = {"workload": workload, "kernel": name, "hbm_bytes_per_launch": v["hbm_bytes"],
        "read_bytes": v["hbm_bytes"] - v["WRITE_SIZE_bytes"], "write_bytes": v["WRITE_SIZE_bytes"],
        "FETCH_SIZE_bytes_raw": v["FETCH_SIZE_bytes_raw"], "rdreq": v.get("rdreq"),
-       "source": "profiles/r01_bench_pmc_traffic.json (rocprofv3 --pmc, separate passes for FETCH_SIZE, WRITE_SIZE "
+       "profile": os.path.relpath(os.path.abspath(summary), os.path.dirname(os.path.dirname(os.path.abspath(__file__)))),
+       "source": "rocprofv3 --pmc, separate passes for FETCH_SIZE, WRITE_SIZE "
                  "and TCC_EA0_RDREQ by size; reads = 128-B requests x 128 = 2 x FETCH_SIZE on gfx950; "
                  "tools/profile_bench.sh, tools/profile_summary.py)"}
 root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+hsh = hashlib.sha256()
+for f in sorted(glob.glob(os.path.join(root, "dealii-cuda_amd", "csrc", "*")) + [os.path.join(root, "include", "mfgpu.h")]):
+    hsh.update(open(f, "rb").read())
+out["csrc_sha16"] = hsh.hexdigest()[:16]
 json.dump(out, open(os.path.join(root, "profiles", "traffic_latest.json"), "w"), indent=1)
 print(name, out["hbm_bytes_per_launch"])
