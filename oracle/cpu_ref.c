@@ -218,6 +218,15 @@ int cpu_ref_vmult(int dim, int n, uint32_t n_dofs, const uint32_t *l2g, const do
   return nthreads;
 }
 
+/* number of OpenMP threads of the following calls (0: the runtime's default) */
+void cpu_ref_set_threads(int n) {
+#ifdef _OPENMP
+  if (n > 0) omp_set_num_threads(n);
+#else
+  (void)n;
+#endif
+}
+
 /* bmop-cpu.cc:137-155: dst = init; n_iter x { swap(dst,src); vmult(dst,src) }.  a, b: two vectors;
  * returns 0 if the result is in a, 1 if in b. */
 int cpu_ref_bmop(int dim, int n, uint32_t n_dofs, const uint32_t *l2g, const double *coef, const double *jxw,

@@ -20,6 +20,31 @@ def lib():
     return _lib
 
 
+def cpu_share():
+    """CPUs this process may actually use: the affinity mask, capped by the cgroup CPU quota (a container on a
+    128-thread host may own 16 of them: 128 OpenMP threads would then time-share 16 cores)."""
+    n = len(os.sched_getaffinity(0))
+    for path in ("/sys/fs/cgroup/cpu.max", "/sys/fs/cgroup/cpu/cpu.cfs_quota_us"):
+        try:
+            txt = open(path).read().split()
+            if path.endswith("cpu.max"):
+                if txt[0] != "max":
+                    n = min(n, max(1, int(int(txt[0]) / int(txt[1]))))
+            else:
+                q = int(txt[0])
+                per = int(open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read())
+                if q > 0:
+                    n = min(n, max(1, q // per))
+            break
+        except (OSError, ValueError, IndexError):
+            continue
+    return n
+
+
+def set_threads(n):
+    lib().cpu_ref_set_threads(int(n))
+
+
 def greedy_cell_colors(loc2glob, n_dofs):
     """cell colouring with no shared dof inside a colour (stand-in for deal.II partition_color)."""
     nc = loc2glob.shape[0]
