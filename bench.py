@@ -91,6 +91,8 @@ def main():
     ap.add_argument("--float", action="store_true", help="BMOP_USE_FLOATS")
     ap.add_argument("--mode", default="p2p", choices=["p2p", "pair", "allreduce"])
     ap.add_argument("--no-cpu", action="store_true")
+    ap.add_argument("--kernel", default="auto", choices=["auto", "pencils", "pencils_x", "planes"],
+                    help="mfgpu_desc.kernel: cell-loop kernel family (measurements; the default is the library's choice)")
     ap.add_argument("--batch-cells", type=int, default=0)
     ap.add_argument("--batch-dofs", type=int, default=0)
     ap.add_argument("--colored", action="store_true", help="coloured-scatter mode instead of two-pass")
@@ -128,6 +130,8 @@ def main():
         mesh = mf.Mesh.uniform(3, p, n_glob, slab=(zb, ze), number_type=nt)
     mesh.desc.max_cells_per_batch = args.batch_cells
     mesh.desc.max_dofs_per_batch = args.batch_dofs
+    mesh.desc.kernel = {"auto": mf.KERNEL_AUTO, "pencils": mf.KERNEL_PENCILS, "pencils_x": mf.KERNEL_PENCILS_X,
+                        "planes": mf.KERNEL_PLANES}[args.kernel]
     if args.colored:
         mesh.desc.flags |= mf.COLORED_SCATTER
     if args.general_jacobian:
@@ -221,7 +225,7 @@ def main():
             if (tr.get("workload") == f"p{p}_3d_n{n_glob}_{'f32' if args.float else 'f64'}" and world == 1
                     and op.kernel_name() + "<" in tr.get("kernel", "") and tr.get("csrc_sha16") == csrc_sha16()
                     and not args.adaptive and not args.colored and not args.batch_cells and not args.batch_dofs
-                    and not args.general_jacobian):
+                    and not args.general_jacobian and args.kernel == "auto"):
                 traffic = tr["hbm_bytes_per_launch"]
                 traffic_source = {"file": "profiles/traffic_latest.json", "profile": tr.get("profile"),
                                   "csrc_sha16": tr.get("csrc_sha16")}

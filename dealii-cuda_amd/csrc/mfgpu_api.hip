@@ -500,47 +500,11 @@ int mfgpu_create(const mfgpu_desc *desc, mfgpu_handle **out) {
     return MFGPU_EINVAL;
   }
   mfgpu_handle *h = new mfgpu_handle();
-  // Kernel family (mfgpu_desc.kernel; 0 = the library's choice):
-  //   apply_planes3   3D, uniform-Jacobian path, conforming mesh, two-pass mode, p = 2..4
-  //   apply_batches_x 3D two-pass otherwise (hanging nodes, p = 1, 5, 6)
-  //   apply_batches   2D, and the coloured-scatter mode
-  //   apply_batches_g the general-Jacobian path (no MFGPU_UNIFORM_J0)
-  const bool colored = (d.flags & MFGPU_COLORED_SCATTER) != 0;
-  if (d.kernel > MFGPU_KERNEL_PLANES) {
-    set_error("unknown mfgpu_desc.kernel");
-    delete h;
-    return MFGPU_EINVAL;
-  }
-  h->gk = general;
-  const bool pk_ok = d.dim == 3 && !general && !hn && !colored && d.degree >= 2 && d.degree <= 4 &&
-                     d.n_dofs < (1u << 29);  // (vectors are addressed base + 32-bit byte offset)
-  const bool xk_ok = d.dim == 3 && !general && !colored;
-  if ((d.kernel == MFGPU_KERNEL_PLANES && !pk_ok) || (d.kernel == MFGPU_KERNEL_PENCILS_X && !xk_ok) ||
-      (d.kernel == MFGPU_KERNEL_PENCILS && general)) {
-    set_error("mfgpu_desc.kernel: this kernel family does not cover the description (see include/mfgpu.h)");
-    delete h;
-    return MFGPU_EUNSUPPORTED;
-  }
-  h->pk = pk_ok && (d.kernel == MFGPU_KERNEL_AUTO || d.kernel == MFGPU_KERNEL_PLANES);
-  h->xk = xk_ok && !h->pk && d.kernel != MFGPU_KERNEL_PENCILS;
-  PlanLimits lim;
-  if (h->pk) {
-    lim.max_cells = (uint32_t)p_cells_per_wave(d.degree + 1);
-    lim.max_dofs = (uint32_t)p_kgu(d.degree + 1) * 64u - 1u;
-    lim.interior_max = (uint32_t)p_ji(d.degree + 1) * 64u;
-    lim.halo_stride = (uint32_t)p_hs(d.degree + 1) * 64u;
-    lim.shared_max = lim.halo_stride - 1u;  // the list's last slot stays padding (idle tasks)
-  }
-  // apply_batches_x unrolls 4 chunks at p=3 (64-cell batches = 13^3 dofs like p=4); everything else 3
-  int rc = build_plan(d, h->plan, (h->xk && d.degree == 3) ? 4u : 3u, h->pk ? &lim : nullptr);
-  if (rc == MFGPU_EUNSUPPORTED && h->pk && d.kernel == MFGPU_KERNEL_AUTO && xk_ok) {
-    // a cell with more surface dofs than the plane kernel's dof-list slots hold (cannot happen on conforming
-    // hexahedral meshes): the pencil kernel has no such limit
-    h->pk = false;
-    h->xk = true;
-    h->plan = Plan();
-    rc = build_plan(d, h->plan, d.degree == 3 ? 4u : 3u, nullptr);
-  }
+  KernelChoice kc;
+  int rc = choose_kernel_and_plan(d, kc, h->plan);
+  h->gk = kc.general;
+  h->pk = kc.planes;
+  h->xk = kc.pencils_x;
   if (rc) {
     delete h;
     return rc;

@@ -79,6 +79,18 @@ struct PlanLimits {
 // max_chunks: chunks of cells per batch the cell-loop kernel unrolls (3; apply_batches_x at p=3: 4)
 int build_plan(const mfgpu_desc &d, Plan &plan, uint32_t max_chunks = 3, const PlanLimits *limits = nullptr);
 
+// Which cell-loop kernel family serves a description (mfgpu_desc.kernel; 0 = the library's choice), and the plan
+// built for it -- shared by mfgpu_create and the host-only mfgpu_plan_create:
+//   planes   apply_planes3: 3D, uniform-Jacobian path, conforming mesh, two-pass mode, p = 4 by default
+//            (p = 2, 3 on request: mfgpu_desc.kernel = MFGPU_KERNEL_PLANES)
+//   pencils_x apply_batches_x: 3D two-pass otherwise (hanging nodes, other degrees)
+//   general  apply_batches_g: no MFGPU_UNIFORM_J0
+//   none of them: apply_batches (2D, coloured-scatter mode)
+struct KernelChoice {
+  bool planes = false, pencils_x = false, general = false;
+};
+int choose_kernel_and_plan(const mfgpu_desc &d, KernelChoice &kc, Plan &plan);
+
 // Derive the kernel's 1D tables from the reference-layout tables T[dof*n+q]:
 //   S[i*n+q]  = shape_values (interpolation nodal -> quadrature points)
 //   Dt[q*n+t] = l_t'(x_q): collocation derivative on the quadrature points, from

@@ -171,9 +171,15 @@ int build_plan(const mfgpu_desc &d, Plan &P, uint32_t max_chunks, const PlanLimi
 
   // ---- greedy batching: grow from the lowest unassigned cell, always adding the candidate that
   // shares most dofs with the batch (ties: earliest discovered), until a limit is hit.
+  // With limits->interior_max (apply_planes3) a batch must also keep its SURFACE within the pass-2 slots of the dof
+  // list: surface = dofs with an incident cell outside the batch, or constrained, plus the interior dofs beyond
+  // interior_max.  The surface is not monotone in the number of cells, so growth runs to the cell / dof limit and
+  // the batch is then cut back to the longest prefix of its growth order that satisfied the bound.
   constexpr uint32_t NONE = 0xffffffffu;
+  const bool bound_surface = limits && limits->interior_max;
   std::vector<uint32_t> cell_batch(nc, NONE);
   std::vector<uint32_t> dof_stamp(N, NONE);   // batch id that already contains this dof
+  std::vector<uint32_t> inc_cnt(bound_surface ? N : 0, 0);  // incident cells of the dof inside the current batch
   std::vector<uint32_t> gain(nc, 0), gain_stamp(nc, NONE);
   std::vector<uint32_t> cand;
   std::vector<std::vector<uint32_t>> batches;
@@ -185,7 +191,8 @@ int build_plan(const mfgpu_desc &d, Plan &P, uint32_t max_chunks, const PlanLimi
     batches.emplace_back();
     std::vector<uint32_t> &cells = batches.back();
     cand.clear();
-    uint32_t ndofs = 0;
+    uint32_t ndofs = 0, n_enclosed = 0;
+    size_t last_ok = 0;
     uint32_t next = seed;
     while (true) {
       // add `next`
@@ -193,7 +200,17 @@ int build_plan(const mfgpu_desc &d, Plan &P, uint32_t max_chunks, const PlanLimi
       cells.push_back(next);
       for (uint32_t i = 0; i < nd; ++i) {
         const uint32_t g = l2g[(uint64_t)next * nd + i];
-        if (dof_stamp[g] == b) continue;
+        const bool first = dof_stamp[g] != b;
+        if (bound_surface) {
+          // (a cell listing one dof twice counts once: compare with the previous entries of this cell)
+          bool dup = false;
+          for (uint32_t i2 = 0; i2 < i && !dup; ++i2) dup = l2g[(uint64_t)next * nd + i2] == g;
+          if (!dup) {
+            if (first) inc_cnt[g] = 0;
+            if (++inc_cnt[g] == dc_off[g + 1] - dc_off[g] && !constrained[g]) ++n_enclosed;
+          }
+        }
+        if (!first) continue;
         dof_stamp[g] = b;
         ++ndofs;
         if (Bmax == 1) continue;
@@ -208,6 +225,8 @@ int build_plan(const mfgpu_desc &d, Plan &P, uint32_t max_chunks, const PlanLimi
           gain[c2]++;
         }
       }
+      if (!bound_surface || ndofs - std::min(n_enclosed, limits->interior_max) <= limits->shared_max)
+        last_ok = cells.size();
       if (cells.size() >= Bmax) break;
       // pick best candidate
       uint32_t best = NONE, best_gain = 0;
@@ -226,6 +245,10 @@ int build_plan(const mfgpu_desc &d, Plan &P, uint32_t max_chunks, const PlanLimi
       if (ndofs + (nd - best_gain) > NBmax) break;
       next = best;
     }
+    if (last_ok == 0) last_ok = 1;  // (a single cell over the bound is reported by the classification below)
+    for (size_t k = last_ok; k < cells.size(); ++k) cell_batch[cells[k]] = NONE;
+    cells.resize(last_ok);
+    if (seed < nc && cell_batch[seed] != b) seed = 0;  // defensive: the seed is the first cell of its batch
   }
   uint32_t nb = (uint32_t)batches.size();
   // cells with a hanging-node mask first: the kernel takes the extra interpolation stages for a whole
@@ -469,6 +492,46 @@ int build_plan(const mfgpu_desc &d, Plan &P, uint32_t max_chunks, const PlanLimi
   return 0;
 }
 
+int choose_kernel_and_plan(const mfgpu_desc &d, KernelChoice &kc, Plan &plan) {
+  const bool general = !(d.flags & MFGPU_UNIFORM_J0), hn = (d.flags & MFGPU_HANGING_NODES) != 0;
+  const bool colored = (d.flags & MFGPU_COLORED_SCATTER) != 0;
+  if (d.kernel > MFGPU_KERNEL_PLANES) {
+    set_error("unknown mfgpu_desc.kernel");
+    return MFGPU_EINVAL;
+  }
+  const bool pk_ok = d.dim == 3 && !general && !hn && !colored && d.degree >= 2 && d.degree <= 4 &&
+                     d.n_dofs < (1u << 29);  // (vectors are addressed base + 32-bit byte offset)
+  const bool xk_ok = d.dim == 3 && !general && !colored;
+  if ((d.kernel == MFGPU_KERNEL_PLANES && !pk_ok) || (d.kernel == MFGPU_KERNEL_PENCILS_X && !xk_ok) ||
+      (d.kernel == MFGPU_KERNEL_PENCILS && general)) {
+    set_error("mfgpu_desc.kernel: this kernel family does not cover the description (see include/mfgpu.h)");
+    return MFGPU_EUNSUPPORTED;
+  }
+  kc.general = general;
+  // by default the plane kernel serves p = 4 only: at p = 2, 3 the pencil kernel measures faster
+  kc.planes = pk_ok && (d.kernel == MFGPU_KERNEL_PLANES || (d.kernel == MFGPU_KERNEL_AUTO && d.degree == 4));
+  kc.pencils_x = xk_ok && !kc.planes && d.kernel != MFGPU_KERNEL_PENCILS;
+  PlanLimits lim;
+  if (kc.planes) {
+    lim.max_cells = (uint32_t)p_cells_per_wave(d.degree + 1);
+    lim.max_dofs = (uint32_t)p_kgu(d.degree + 1) * 64u - 1u;
+    lim.interior_max = (uint32_t)p_ji(d.degree + 1) * 64u;
+    lim.halo_stride = (uint32_t)p_hs(d.degree + 1) * 64u;
+    lim.shared_max = lim.halo_stride - 1u;  // the list's last slot stays padding (idle tasks)
+  }
+  // apply_batches_x unrolls 4 chunks at p=3 (64-cell batches = 13^3 dofs like p=4); everything else 3
+  int rc = build_plan(d, plan, (kc.pencils_x && d.degree == 3) ? 4u : 3u, kc.planes ? &lim : nullptr);
+  if (rc == MFGPU_EUNSUPPORTED && kc.planes && d.kernel == MFGPU_KERNEL_AUTO && xk_ok) {
+    // a cell with more surface dofs than the plane kernel's dof-list slots hold (cannot happen on conforming
+    // hexahedral meshes): the pencil kernel has no such limit
+    kc.planes = false;
+    kc.pencils_x = true;
+    plan = Plan();
+    rc = build_plan(d, plan, d.degree == 3 ? 4u : 3u, nullptr);
+  }
+  return rc;
+}
+
 }  // namespace mfgpu
 
 extern "C" {
@@ -481,7 +544,8 @@ int mfgpu_plan_create(const mfgpu_desc *desc, mfgpu_plan **out) {
     return MFGPU_EINVAL;
   }
   mfgpu_plan *p = new mfgpu_plan();
-  int rc = mfgpu::build_plan(*desc, p->plan);
+  mfgpu::KernelChoice kc;
+  int rc = mfgpu::choose_kernel_and_plan(*desc, kc, p->plan);
   if (rc) {
     delete p;
     return rc;

@@ -67,7 +67,10 @@ def test_c1_sizes():
     assert (m.n_cells, m.n_dofs, m.desc.n_constrained) == (1024, 4225, 256)
 
 
-def _plan_invariants(od, plan, colored=False):
+def _plan_invariants(od, plan, colored=False, planes=False):
+    """planes: the plan of apply_planes3 (mfgpu_desc.kernel = PLANES, or the default at p = 4 in 3D): constrained dofs
+    and the interior dofs beyond the dof list's interior slots take the pass-2 route although one batch touches them,
+    every batch owns a fixed number of halo slots and at least one pass-2 dof."""
     nd = od.nd
     bco, bdo, cbo = plan.batch_cell_off, plan.batch_dof_off, plan.color_batch_off
     order, bdofs, bflags, lmap = plan.cell_order, plan.bdofs, plan.bflags, plan.lmap
@@ -85,16 +88,25 @@ def _plan_invariants(od, plan, colored=False):
         ntouch[bdofs[bdo[b]:bdo[b + 1]]] += 1
     # shared-dof CSR of the two-pass mode
     sd, so, si = plan.sdofs, plan.s_off, plan.s_idx
-    np.testing.assert_array_equal(np.sort(sd & 0x7fffffff), np.nonzero(ntouch >= 2)[0])
+    sdg = sd & 0x7fffffff
+    if planes:
+        assert set(np.nonzero(ntouch >= 2)[0].tolist()) <= set(sdg.tolist()) and len(np.unique(sdg)) == len(sdg)
+        assert (con[sdg[ntouch[sdg] == 1]] | True).all()
+        assert set(np.nonzero(con & (ntouch >= 1))[0].tolist()) <= set(sdg.tolist())  # every touched constrained dof
+        assert len(set(si.tolist())) == len(si) and (si < plan.halo_off[-1]).all()   # distinct halo slots
+    else:
+        np.testing.assert_array_equal(np.sort(sdg), np.nonzero(ntouch >= 2)[0])
+        assert sorted(si.tolist()) == list(range(int(plan.halo_off[-1])))   # every halo slot read exactly once
     np.testing.assert_array_equal(np.diff(so), ntouch[sd & 0x7fffffff])
-    assert sorted(si.tolist()) == list(range(int(plan.halo_off[-1])))   # every halo slot read exactly once
+    on_route2 = np.zeros(od.n_dofs, bool)
+    on_route2[sdg] = True
     # grouped form of the same pass: chunks of <= 64 consecutive shared dofs with one toucher set; partial t
     # of the chunk's lane l sits at gstarts[tstart + t] + offset + l -- must reproduce the CSR exactly
     ch, gs = plan.chunks, plan.gstarts
     covered = np.zeros(len(sd), int)
     for pos, ck, ts, off in ch.tolist():
         cnt, k = ck & 0xffff, ck >> 16
-        assert 1 <= cnt <= 64 and k >= 2
+        assert 1 <= cnt <= 64 and (k >= 2 or planes)
         covered[pos:pos + cnt] += 1
         for lane in range(cnt):
             i = pos + lane
@@ -109,8 +121,14 @@ def _plan_invariants(od, plan, colored=False):
             ni = int(plan.batch_nint[b])
             assert (np.diff(g[:ni].astype(np.int64)) > 0).all()     # [interior asc | shared, grouped], unique
             assert len(np.unique(g)) == len(g)
-            assert (ntouch[g[:ni]] == 1).all() and (ntouch[g[ni:]] >= 2).all()
-            assert plan.halo_off[b + 1] - plan.halo_off[b] == len(g) - ni
+            assert (ntouch[g[:ni]] == 1).all() and not on_route2[g[:ni]].any() and on_route2[g[ni:]].all()
+            if planes:
+                assert len(g) > ni and not con[g[:ni]].any()
+                assert plan.halo_off[b + 1] - plan.halo_off[b] >= len(g) - ni + 1
+                assert plan.halo_off[b + 1] - plan.halo_off[b] == plan.halo_off[1] - plan.halo_off[0]
+            else:
+                assert (ntouch[g[ni:]] >= 2).all()
+                assert plan.halo_off[b + 1] - plan.halo_off[b] == len(g) - ni
             assert not (colored and seen[g].any())                   # colour is conflict-free
             seen[g] = True
             np.testing.assert_array_equal((f & 1).astype(bool), con[g])
@@ -136,7 +154,7 @@ def test_plan_invariants_and_dataflow(dim, p, n, kw):
     rng = np.random.default_rng(0)
     x, y0 = rng.standard_normal(od.n_dofs), rng.standard_normal(od.n_dofs)
     for colored in (False, True):  # two-pass plan (spatial batch order) / coloured plan (colour-major order)
-        desc, keep = desc_from_oracle(od, colored=colored, **kw)
+        desc, keep = desc_from_oracle(od, colored=colored, kernel=mf.KERNEL_PENCILS, **kw)
         plan = mf.Plan(desc, keep)
         _plan_invariants(od, plan, colored)
         ref = o.vmult(od, x)
@@ -145,6 +163,26 @@ def test_plan_invariants_and_dataflow(dim, p, n, kw):
         ref = o.vmult_add(od, y0, x)
         for tp in (False, True):
             np.testing.assert_allclose(emulate_plan_vmult(od, plan, x, y0, twopass=tp), ref, rtol=0, atol=1e-12 * np.abs(ref).max())
+
+
+@pytest.mark.parametrize("p,n,kw", [(4, 3, {}), (4, 5, {}), (4, 4, dict(max_cells_per_batch=5)), (3, 5, {}), (2, 6, {}),
+                                    (2, 4, dict(max_cells_per_batch=1))])
+def test_plane_plan_invariants_and_dataflow(p, n, kw):
+    """the plan apply_planes3 runs on (fixed slot structure of the dof lists, demotions to the pass-2 route, batches
+    cut back to their surface bound): invariants, and the numpy emulation of its data flow against the oracle"""
+    od = o.uniform_mesh_desc(3, p, n)
+    rng = np.random.default_rng(0)
+    x, y0 = rng.standard_normal(od.n_dofs), rng.standard_normal(od.n_dofs)
+    desc, keep = desc_from_oracle(od, kernel=mf.KERNEL_PLANES, **kw)
+    plan = mf.Plan(desc, keep)
+    _plan_invariants(od, plan, False, planes=True)
+    nbd, ni = np.diff(plan.batch_dof_off), plan.batch_nint
+    ji, hs = {3: (2, 3), 4: (5, 6), 5: (9, 9)}[p + 1]  # p_ji, p_hs of mfgpu_internal.h
+    assert (np.diff(plan.batch_cell_off) <= 64 // (p + 1)).all() and (ni <= 64 * ji).all() and (nbd - ni < 64 * hs).all()
+    ref = o.vmult(od, x)
+    np.testing.assert_allclose(emulate_plan_vmult(od, plan, x, twopass=True), ref, rtol=0, atol=1e-12 * np.abs(ref).max())
+    ref = o.vmult_add(od, y0, x)
+    np.testing.assert_allclose(emulate_plan_vmult(od, plan, x, y0, twopass=True), ref, rtol=0, atol=1e-12 * np.abs(ref).max())
 
 
 def test_plan_orphans_and_ragged_mesh():
@@ -165,9 +203,10 @@ def test_plan_orphans_and_ragged_mesh():
 
 
 def test_batching_quality_structured():
-    """greedy batching should find compact 3x3x3 blocks on a structured p=4 mesh"""
+    """greedy batching should find compact 3x3x3 blocks on a structured p=4 mesh (pencil kernels), and exact
+    3x2x2 boxes, long side along x, for the plane kernel (12 cells = one wave)"""
     od = o.uniform_mesh_desc(3, 4, 9)
-    desc, keep = desc_from_oracle(od, max_cells_per_batch=27)
+    desc, keep = desc_from_oracle(od, max_cells_per_batch=27, kernel=mf.KERNEL_PENCILS_X)
     plan = mf.Plan(desc, keep)
     nb = len(plan.batch_cell_off) - 1
     assert nb == 27, nb
@@ -180,6 +219,15 @@ def test_batching_quality_structured():
                                           for bz in range(3) for by in range(3) for bx in range(3)])
     desc, keep = desc_from_oracle(od, max_cells_per_batch=27, colored=True)
     assert len(mf.Plan(desc, keep).color_batch_off) - 1 == 8
+    od = o.uniform_mesh_desc(3, 4, 12)
+    desc, keep = desc_from_oracle(od)  # the default at p = 4: apply_planes3
+    plan = mf.Plan(desc, keep)
+    assert len(plan.batch_cell_off) - 1 == 12 ** 3 // 12
+    for b in range(len(plan.batch_cell_off) - 1):
+        cells = plan.cell_order[plan.batch_cell_off[b]:plan.batch_cell_off[b + 1]].astype(np.int64)
+        ext = [int(np.ptp(cells // 12 ** d % 12)) + 1 for d in range(3)]
+        assert ext == [3, 2, 2], ext
+    assert np.diff(plan.batch_dof_off).max() == 13 * 9 * 9 and plan.batch_nint.max() == 11 * 7 * 7
 
 
 def test_slab_meshes_tile_the_global_mesh():

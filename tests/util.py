@@ -56,7 +56,7 @@ def emulate_plan_vmult(od: o.Desc, plan: "mf.Plan", src, dst_in=None, twopass=Fa
             gi, ci = g[:ni], con[:ni]
             val = np.where(ci, src[gi], acc[:ni])
             dst[gi] = (dst[gi] if add else 0.0) + val
-            halo[hoff[b]:hoff[b + 1]] = acc[ni:]
+            halo[hoff[b]:hoff[b] + len(acc) - ni] = acc[ni:]  # (plane plans: hoff[b + 1] - hoff[b] is a fixed stride)
             continue
         first_con = con & ~addf
         dst[g[first_con]] = (dst[g[first_con]] if add else 0.0) + src[g[first_con]]
