@@ -49,7 +49,8 @@ struct mfgpu_handle {
   void *d_halo = nullptr;
   unsigned long long *d_stamps = nullptr;  // diagnostic build only
   size_t lds = 0, device_bytes = 0;
-  uint32_t max_grid = 0;  // resident workgroups of the cell-loop kernel
+  uint32_t max_grid = 0;    // resident workgroups of the cell-loop kernel
+  uint32_t max_grid_p = 0;  // ... of apply_planes3 (its batches: the first plan.n_plane_batches)
   bool xk = false;        // 3D two-pass kernel for three workgroups per CU (apply_batches_x)
   bool gk = false;        // general-Jacobian kernel (apply_batches_g)
   bool pk = false;        // plane-per-thread kernel (apply_planes3): 3D uniform-Jacobian default for p = 2..4
@@ -160,7 +161,7 @@ int create_typed(mfgpu_handle *h, const mfgpu_desc &d) {
     // the list's last slot, which is padding in every batch the planner accepts.
     const int n = P.n, n2 = n * n, NT = p_cells_per_wave(n) * n, NIW = (n2 + 1) / 2;
     const int JI = p_ji(n) * 64, NB = p_kgu(n) * 64;
-    const size_t nbat = P.batch_cell_off.size() - 1;
+    const size_t nbat = P.n_plane_batches;
     const uint32_t dummy = 8u * (uint32_t)(NB - 1);
     std::vector<uint32_t> bd((size_t)NB * nbat), ix((size_t)NIW * NT * nbat, dummy | (dummy << 16));
     std::vector<uint32_t> slot_of;  // batch-local id (position in P.bdofs) -> slot
@@ -264,8 +265,9 @@ int create_typed(mfgpu_handle *h, const mfgpu_desc &d) {
     // the folded coefficient again, per batch [row y + n z][task]: the layout of stage B of apply_planes3
     // (d_coef in plan cell order stays: the diagonal kernel reads it)
     const int n = P.n, NT = p_cells_per_wave(n) * n;
-    const size_t nbat = P.batch_cell_off.size() - 1, total = nbat * (size_t)(n * n) * NT;
-    std::vector<uint32_t> cb(ncell), cp(ncell);
+    const size_t nbat = P.n_plane_batches, total = nbat * (size_t)(n * n) * NT;
+    const size_t ncell_p = P.batch_cell_off[nbat];  // the plane batches' cells come first in plan order
+    std::vector<uint32_t> cb(ncell_p), cp(ncell_p);
     for (size_t b = 0; b < nbat; ++b)
       for (uint32_t c = P.batch_cell_off[b]; c < P.batch_cell_off[b + 1]; ++c) {
         cb[c] = (uint32_t)b;
@@ -273,8 +275,8 @@ int create_typed(mfgpu_handle *h, const mfgpu_desc &d) {
       }
     uint32_t *t_cb = nullptr, *t_cp = nullptr;
     size_t tmp2 = 0;
-    rc = dev_upload(&t_cb, cb.data(), ncell * 4, tmp2);
-    if (!rc) rc = dev_upload(&t_cp, cp.data(), ncell * 4, tmp2);
+    rc = dev_upload(&t_cb, cb.data(), ncell_p * 4, tmp2);
+    if (!rc) rc = dev_upload(&t_cp, cp.data(), ncell_p * 4, tmp2);
     if (!rc) {
       hipError_t e2 = hipMalloc(&h->d_coefp, total * sizeof(T));
       if (e2 == hipSuccess) {
@@ -282,7 +284,7 @@ int create_typed(mfgpu_handle *h, const mfgpu_desc &d) {
         e2 = hipMemset(h->d_coefp, 0, total * sizeof(T));
       }
       if (e2 == hipSuccess)
-        e2 = relayout_coef_launch<T>((T *)h->d_coefp, (const T *)h->d_coef, t_cb, t_cp, ncell * nd, n, nullptr);
+        e2 = relayout_coef_launch<T>((T *)h->d_coefp, (const T *)h->d_coef, t_cb, t_cp, ncell_p * nd, n, nullptr);
       if (e2 == hipSuccess) e2 = hipDeviceSynchronize();
       if (e2 != hipSuccess) {
         set_error(std::string("coefficient relayout: ") + hipGetErrorString(e2));
@@ -295,11 +297,15 @@ int create_typed(mfgpu_handle *h, const mfgpu_desc &d) {
     ApplyArgs<T> dummy{};
     int per_cu = 0, dev = 0;
     hipDeviceProp_t prop;
-    HIP_TRY(p_launch<T>(P.n, dummy, nullptr, nullptr, 0, nullptr, true, &h->lds, &per_cu));
+    size_t lds_p = 0;
+    HIP_TRY(p_launch<T>(P.n, dummy, nullptr, nullptr, 0, nullptr, true, &lds_p, &per_cu));
     HIP_TRY(hipGetDevice(&dev));
     HIP_TRY(hipGetDeviceProperties(&prop, dev));
-    h->max_grid = (uint32_t)(per_cu < 1 ? 1 : per_cu) * (uint32_t)prop.multiProcessorCount;
-    return 0;
+    h->max_grid_p = (uint32_t)(per_cu < 1 ? 1 : per_cu) * (uint32_t)prop.multiProcessorCount;
+    if (!h->xk) {
+      h->lds = lds_p;
+      return 0;
+    }
   }
   // persistent grid: as many workgroups as fit on the chip (each loops over its batches)
   ApplyArgs<T> dummy{};
@@ -378,18 +384,25 @@ int vmult_typed(mfgpu_handle *h, void *dst, const void *src, hipStream_t st, int
       HIP_TRY(hipEventRecord(h->ev[h->ev_used], st));
     }
     a.batch_end = a.batch0 + nbat;
-    if (h->pk)
-      HIP_TRY(p_launch<T>(P.n, a, h->S.data(), h->Dt.data(), nbat < h->max_grid ? nbat : h->max_grid, st, false,
-                          nullptr, nullptr));
-    else if (h->gk)
-      HIP_TRY(g_launch<T>(P.n, a, h->S.data(), h->Dt.data(), h->hn, nbat < h->max_grid ? nbat : h->max_grid, st, false,
-                          nullptr, nullptr));
+    if (h->pk) {  // the batches of cells without a hanging-node mask (all batches on conforming meshes)
+      ApplyArgs<T> ap = a;
+      ap.batch_end = P.n_plane_batches;
+      HIP_TRY(p_launch<T>(P.n, ap, h->S.data(), h->Dt.data(),
+                          P.n_plane_batches < h->max_grid_p ? P.n_plane_batches : h->max_grid_p, st, false, nullptr,
+                          nullptr));
+      a.batch0 = P.n_plane_batches;
+    }
+    const uint32_t nrest = a.batch_end - a.batch0;
+    if (nrest == 0) {
+    } else if (h->gk)
+      HIP_TRY(g_launch<T>(P.n, a, h->S.data(), h->Dt.data(), h->hn, nrest < h->max_grid ? nrest : h->max_grid, st,
+                          false, nullptr, nullptr));
     else if (h->xk)
-      HIP_TRY(x_launch<T>(P.n, a, h->S.data(), h->Dt.data(), h->hn, nbat < h->max_grid ? nbat : h->max_grid, st,
+      HIP_TRY(x_launch<T>(P.n, a, h->S.data(), h->Dt.data(), h->hn, nrest < h->max_grid ? nrest : h->max_grid, st,
                           false, nullptr, nullptr));
     else
       HIP_TRY(apply_launch<T>(P.dim, P.n, a, h->S.data(), h->Dt.data(), h->hn, h->twopass,
-                              nbat < h->max_grid ? nbat : h->max_grid, st));
+                              nrest < h->max_grid ? nrest : h->max_grid, st));
     if (h->prof) {
       HIP_TRY(hipEventRecord(h->ev[h->ev_used + 1], st));
       h->ev_used += 2;
@@ -617,7 +630,8 @@ int mfgpu_plan_stats(const mfgpu_handle *h, uint64_t s[8]) {
 
 const char *mfgpu_kernel_name(const mfgpu_handle *h) {
   if (!h) return "";
-  return h->pk ? "apply_planes3" : h->gk ? "apply_batches_g" : h->xk ? "apply_batches_x" : "apply_batches";
+  return h->pk ? (h->xk ? "apply_planes3+apply_batches_x" : "apply_planes3")
+               : h->gk ? "apply_batches_g" : h->xk ? "apply_batches_x" : "apply_batches";
 }
 
 int mfgpu_profile_enable(mfgpu_handle *h, int on) {

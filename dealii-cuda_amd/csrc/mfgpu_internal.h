@@ -62,6 +62,7 @@ struct Plan {
   std::vector<uint32_t> chunks;           // [4 * n_chunks] {sdofs position, count | k << 16, gstarts offset, offset in group}
   std::vector<uint32_t> gstarts;          // per group: halo slot of its first dof in each of its k touchers
   uint32_t max_batch_dofs = 0, max_batch_cells = 0;
+  uint32_t n_plane_batches = 0;  // the first n_plane_batches batches run in apply_planes3, the rest in apply_batches_x
   uint64_t n_first = 0, n_add = 0;
 };
 
@@ -73,6 +74,9 @@ struct PlanLimits {
   // never constrained); the rest -- at most shared_max, else the plan fails with MFGPU_EUNSUPPORTED -- takes the
   // pass-2 route, and every batch has at least one pass-2 dof; every batch owns halo_stride halo slots
   uint32_t interior_max = 0, shared_max = 0, halo_stride = 0;
+  // meshes with hanging nodes: batches of unmasked cells only (plane kernel) first, then batches of masked cells
+  // under the pencil kernel's limits (see build_plan)
+  bool segregate_masked = false;
 };
 
 // Build the plan from a description (validates it).  Returns 0 or MFGPU_E*.
@@ -81,9 +85,10 @@ int build_plan(const mfgpu_desc &d, Plan &plan, uint32_t max_chunks = 3, const P
 
 // Which cell-loop kernel family serves a description (mfgpu_desc.kernel; 0 = the library's choice), and the plan
 // built for it -- shared by mfgpu_create and the host-only mfgpu_plan_create:
-//   planes   apply_planes3: 3D, uniform-Jacobian path, conforming mesh, two-pass mode, p = 4 by default
-//            (p = 2, 3 on request: mfgpu_desc.kernel = MFGPU_KERNEL_PLANES)
-//   pencils_x apply_batches_x: 3D two-pass otherwise (hanging nodes, other degrees)
+//   planes   apply_planes3: 3D, uniform-Jacobian path, two-pass mode, p = 4 by default (p = 2, 3 on request:
+//            mfgpu_desc.kernel = MFGPU_KERNEL_PLANES); on meshes with hanging nodes it takes the batches of cells
+//            without a constraint mask (Plan::n_plane_batches) and pencils_x is set as well for the others
+//   pencils_x apply_batches_x: 3D two-pass otherwise
 //   general  apply_batches_g: no MFGPU_UNIFORM_J0
 //   none of them: apply_batches (2D, coloured-scatter mode)
 struct KernelChoice {

@@ -134,6 +134,13 @@ int build_plan(const mfgpu_desc &d, Plan &P, uint32_t max_chunks, const PlanLimi
     set_error("n_dofs >= 2^31 is not supported (bit 31 of the dof lists carries the constrained flag)");
     return MFGPU_EUNSUPPORTED;
   }
+  // limits->segregate_masked (meshes with hanging nodes under apply_planes3): cells WITHOUT a hanging-node mask are
+  // batched under `limits` and run in the plane kernel, which has no constraint stages; cells with a mask get batches of
+  // their own under the pencil kernel's default limits (Bmax1, NBmax1) and run in apply_batches_x<HN>.  The plane
+  // batches come first in the execution order (P.n_plane_batches of them).
+  const bool segregate = limits && limits->segregate_masked && (d.flags & MFGPU_HANGING_NODES) && d.constraint_mask;
+  uint32_t Bmax1 = 0, NBmax1 = 0;
+  if (segregate) default_batch_limits(d, max_chunks, Bmax1, NBmax1);
   uint32_t Bmax, NBmax;
   if (limits && limits->max_cells && limits->max_dofs) {
     // kernel-imposed limits; the caller's knobs may only tighten them
@@ -176,10 +183,12 @@ int build_plan(const mfgpu_desc &d, Plan &P, uint32_t max_chunks, const PlanLimi
   // interior_max.  The surface is not monotone in the number of cells, so growth runs to the cell / dof limit and
   // the batch is then cut back to the longest prefix of its growth order that satisfied the bound.
   constexpr uint32_t NONE = 0xffffffffu;
-  const bool bound_surface = limits && limits->interior_max;
+  const bool bound_surface_any = limits && limits->interior_max;
+  auto masked = [&](uint32_t c) { return segregate && d.constraint_mask[c] != 0; };
+  std::vector<uint8_t> batch_masked;  // per batch: class of its cells (segregate only)
   std::vector<uint32_t> cell_batch(nc, NONE);
   std::vector<uint32_t> dof_stamp(N, NONE);   // batch id that already contains this dof
-  std::vector<uint32_t> inc_cnt(bound_surface ? N : 0, 0);  // incident cells of the dof inside the current batch
+  std::vector<uint32_t> inc_cnt(bound_surface_any ? N : 0, 0);  // incident cells of the dof inside the current batch
   std::vector<uint32_t> gain(nc, 0), gain_stamp(nc, NONE);
   std::vector<uint32_t> cand;
   std::vector<std::vector<uint32_t>> batches;
@@ -190,6 +199,10 @@ int build_plan(const mfgpu_desc &d, Plan &P, uint32_t max_chunks, const PlanLimi
     const uint32_t b = (uint32_t)batches.size();
     batches.emplace_back();
     std::vector<uint32_t> &cells = batches.back();
+    const bool cls = masked(seed);
+    batch_masked.push_back(cls);
+    const bool bound_surface = bound_surface_any && !cls;
+    const uint32_t Bmax_b = cls ? Bmax1 : Bmax, NBmax_b = cls ? NBmax1 : NBmax;
     cand.clear();
     uint32_t ndofs = 0, n_enclosed = 0;
     size_t last_ok = 0;
@@ -213,10 +226,10 @@ int build_plan(const mfgpu_desc &d, Plan &P, uint32_t max_chunks, const PlanLimi
         if (!first) continue;
         dof_stamp[g] = b;
         ++ndofs;
-        if (Bmax == 1) continue;
+        if (Bmax_b == 1) continue;
         for (uint32_t k = dc_off[g]; k < dc_off[g + 1]; ++k) {
           const uint32_t c2 = dc[k];
-          if (cell_batch[c2] != NONE) continue;
+          if (cell_batch[c2] != NONE || masked(c2) != cls) continue;
           if (gain_stamp[c2] != b) {
             gain_stamp[c2] = b;
             gain[c2] = 0;
@@ -227,7 +240,7 @@ int build_plan(const mfgpu_desc &d, Plan &P, uint32_t max_chunks, const PlanLimi
       }
       if (!bound_surface || ndofs - std::min(n_enclosed, limits->interior_max) <= limits->shared_max)
         last_ok = cells.size();
-      if (cells.size() >= Bmax) break;
+      if (cells.size() >= Bmax_b) break;
       // pick best candidate
       uint32_t best = NONE, best_gain = 0;
       size_t w = 0;
@@ -242,13 +255,28 @@ int build_plan(const mfgpu_desc &d, Plan &P, uint32_t max_chunks, const PlanLimi
       }
       cand.resize(w);
       if (best == NONE) break;
-      if (ndofs + (nd - best_gain) > NBmax) break;
+      if (ndofs + (nd - best_gain) > NBmax_b) break;
       next = best;
     }
     if (last_ok == 0) last_ok = 1;  // (a single cell over the bound is reported by the classification below)
     for (size_t k = last_ok; k < cells.size(); ++k) cell_batch[cells[k]] = NONE;
     cells.resize(last_ok);
     if (seed < nc && cell_batch[seed] != b) seed = 0;  // defensive: the seed is the first cell of its batch
+  }
+  if (segregate) {  // plane batches first (stable)
+    std::vector<uint32_t> idx(batches.size());
+    std::iota(idx.begin(), idx.end(), 0u);
+    std::stable_sort(idx.begin(), idx.end(), [&](uint32_t a, uint32_t b2) { return batch_masked[a] < batch_masked[b2]; });
+    std::vector<std::vector<uint32_t>> sorted_batches(batches.size());
+    std::vector<uint8_t> sorted_masked(batches.size());
+    for (size_t k = 0; k < idx.size(); ++k) {
+      sorted_batches[k] = std::move(batches[idx[k]]);
+      sorted_masked[k] = batch_masked[idx[k]];
+    }
+    batches.swap(sorted_batches);
+    batch_masked.swap(sorted_masked);
+  } else {
+    batch_masked.assign(batches.size(), 0);
   }
   uint32_t nb = (uint32_t)batches.size();
   // cells with a hanging-node mask first: the kernel takes the extra interpolation stages for a whole
@@ -283,7 +311,7 @@ int build_plan(const mfgpu_desc &d, Plan &P, uint32_t max_chunks, const PlanLimi
         for (uint32_t i = 0; i < nd; ++i) v.push_back(l2g[(uint64_t)c * nd + i]);
       std::sort(v.begin(), v.end());
       v.erase(std::unique(v.begin(), v.end()), v.end());
-      if (v.size() > NBmax || v.size() > 8191u) {
+      if (v.size() > (batch_masked[b] ? NBmax1 : NBmax) || v.size() > 8191u) {
         // (the greedy estimate nd - gain under-counts a cell that lists one dof twice; the kernels hold a batch's
         // dofs in a fixed number of register / LDS slots and byte offsets of batch-local ids in 16 bits)
         set_error("internal: batch exceeds the kernel's dof slots (degenerate loc2glob?)");
@@ -292,8 +320,12 @@ int build_plan(const mfgpu_desc &d, Plan &P, uint32_t max_chunks, const PlanLimi
       for (uint32_t g : v) ntouch[g]++;
     }
     shared_flag.assign(N, 0);
-    for (uint32_t g = 0; g < N; ++g)
-      shared_flag[g] = ntouch[g] >= 2 || (interior_max && ntouch[g] == 1 && constrained[g]);
+    for (uint32_t g = 0; g < N; ++g) shared_flag[g] = ntouch[g] >= 2;
+    if (interior_max)  // constrained dofs a single PLANE batch touches are demoted (the pencil kernel writes its own)
+      for (uint32_t b = 0; b < nb; ++b)
+        if (!batch_masked[b])
+          for (uint32_t g : bd[b])
+            if (ntouch[g] == 1 && constrained[g]) shared_flag[g] = 1;
     nint.assign(nb, 0);
     std::vector<uint32_t> too_big;
     for (uint32_t b = 0; b < nb; ++b) {
@@ -301,7 +333,7 @@ int build_plan(const mfgpu_desc &d, Plan &P, uint32_t max_chunks, const PlanLimi
       std::stable_partition(v.begin(), v.end(), [&](uint32_t g) { return !shared_flag[g]; });
       uint32_t k = 0;
       while (k < v.size() && !shared_flag[v[k]]) ++k;
-      if (interior_max) {
+      if (interior_max && !batch_masked[b]) {
         uint32_t keep = std::min(k, interior_max);
         if (keep == v.size() && keep > 0) --keep;
         for (uint32_t t = keep; t < k; ++t) shared_flag[v[t]] = 1;
@@ -321,6 +353,7 @@ int build_plan(const mfgpu_desc &d, Plan &P, uint32_t max_chunks, const PlanLimi
       std::vector<uint32_t> second(batches[b].begin() + half, batches[b].end());
       batches[b].resize(half);
       batches.insert(batches.begin() + b + 1, std::move(second));
+      batch_masked.insert(batch_masked.begin() + b + 1, (uint8_t)0);
     }
   }
 
@@ -421,7 +454,8 @@ int build_plan(const mfgpu_desc &d, Plan &P, uint32_t max_chunks, const PlanLimi
     const std::vector<uint32_t> &v = bd[b];
     P.batch_nint.push_back(nint[b]);
     // (apply_planes3: every batch owns a fixed number of halo slots, so a slot index follows from the batch index)
-    P.halo_off.push_back(P.halo_off.back() + (interior_max ? limits->halo_stride : (uint32_t)(v.size() - nint[b])));
+    P.halo_off.push_back(P.halo_off.back() +
+                         (interior_max && !batch_masked[b] ? limits->halo_stride : (uint32_t)(v.size() - nint[b])));
     for (uint32_t g : v) {
       uint8_t f = 0;
       if (constrained[g]) f |= kFlagConstrained;
@@ -446,6 +480,9 @@ int build_plan(const mfgpu_desc &d, Plan &P, uint32_t max_chunks, const PlanLimi
     P.max_batch_dofs = std::max<uint32_t>(P.max_batch_dofs, (uint32_t)v.size());
     P.max_batch_cells = std::max<uint32_t>(P.max_batch_cells, (uint32_t)batches[b].size());
   }
+  P.n_plane_batches = 0;
+  if (interior_max)
+    for (uint32_t k = 0; k < nb; ++k) P.n_plane_batches += batch_masked[order[k]] ? 0u : 1u;
   P.orphans.clear();
   for (uint32_t g = 0; g < N; ++g)
     if (!touched[g]) P.orphans.push_back(g | (constrained[g] ? 0x80000000u : 0u));
@@ -499,7 +536,8 @@ int choose_kernel_and_plan(const mfgpu_desc &d, KernelChoice &kc, Plan &plan) {
     set_error("unknown mfgpu_desc.kernel");
     return MFGPU_EINVAL;
   }
-  const bool pk_ok = d.dim == 3 && !general && !hn && !colored && d.degree >= 2 && d.degree <= 4 &&
+  // (with hanging nodes: the cells without a mask run in the plane kernel, the masked ones in apply_batches_x)
+  const bool pk_ok = d.dim == 3 && !general && !colored && d.degree >= 2 && d.degree <= 4 &&
                      d.n_dofs < (1u << 29);  // (vectors are addressed base + 32-bit byte offset)
   const bool xk_ok = d.dim == 3 && !general && !colored;
   if ((d.kernel == MFGPU_KERNEL_PLANES && !pk_ok) || (d.kernel == MFGPU_KERNEL_PENCILS_X && !xk_ok) ||
@@ -518,6 +556,7 @@ int choose_kernel_and_plan(const mfgpu_desc &d, KernelChoice &kc, Plan &plan) {
     lim.interior_max = (uint32_t)p_ji(d.degree + 1) * 64u;
     lim.halo_stride = (uint32_t)p_hs(d.degree + 1) * 64u;
     lim.shared_max = lim.halo_stride - 1u;  // the list's last slot stays padding (idle tasks)
+    lim.segregate_masked = hn;
   }
   // apply_batches_x unrolls 4 chunks at p=3 (64-cell batches = 13^3 dofs like p=4); everything else 3
   int rc = build_plan(d, plan, (kc.pencils_x && d.degree == 3) ? 4u : 3u, kc.planes ? &lim : nullptr);
@@ -528,6 +567,11 @@ int choose_kernel_and_plan(const mfgpu_desc &d, KernelChoice &kc, Plan &plan) {
     kc.pencils_x = true;
     plan = Plan();
     rc = build_plan(d, plan, d.degree == 3 ? 4u : 3u, nullptr);
+  }
+  if (!rc && kc.planes) {
+    const uint32_t nbat = (uint32_t)plan.batch_cell_off.size() - 1;
+    kc.pencils_x = plan.n_plane_batches < nbat;  // the masked cells' batches
+    if (plan.n_plane_batches == 0) kc.planes = false;
   }
   return rc;
 }
