@@ -196,8 +196,15 @@ int create_typed(mfgpu_handle *h, const mfgpu_desc &d) {
     if ((rc = dev_upload(&h->d_batch_nint, P.batch_nint.data(), P.batch_nint.size() * 4, acct))) return rc;
     if ((rc = dev_upload(&h->d_halo_off, P.halo_off.data(), P.halo_off.size() * 4, acct))) return rc;
     {
-      std::vector<uint32_t> arr, tiles;
-      build_pass2_classes(P.sdofs, P.s_off, P.s_idx, arr, tiles);
+      // pass 2 also writes the dofs no cell touches (hanging dofs after substitution: dst = 0, or the identity row of
+      // a constrained one): listed with ONE partial sum, a halo slot behind the batches' that is zero and stays zero
+      std::vector<uint32_t> sd(P.sdofs), so(P.s_off), si(P.s_idx), arr, tiles;
+      for (uint32_t orph : P.orphans) {
+        sd.push_back(orph);
+        si.push_back(P.halo_off.back());
+        so.push_back((uint32_t)si.size());
+      }
+      build_pass2_classes(sd, so, si, arr, tiles);
       h->n_p2tiles = (uint32_t)(tiles.size() / 4);
       if ((rc = dev_upload(&h->d_p2arr, arr.data(), arr.size() * 4, acct))) return rc;
       if ((rc = dev_upload(&h->d_p2tiles, tiles.data(), tiles.size() * 4, acct))) return rc;
@@ -206,7 +213,7 @@ int create_typed(mfgpu_handle *h, const mfgpu_desc &d) {
       set_error("halo buffer too large for 32-bit byte offsets");
       return MFGPU_EUNSUPPORTED;
     }
-    const size_t hb = (size_t)P.halo_off.back() * sizeof(T);
+    const size_t hb = ((size_t)P.halo_off.back() + 1) * sizeof(T);  // + the always-zero slot of the untouched dofs
     if (hb) {
       HIP_TRY(hipMalloc(&h->d_halo, hb));
       HIP_TRY(hipMemset(h->d_halo, 0, hb));
@@ -411,7 +418,8 @@ int vmult_typed(mfgpu_handle *h, void *dst, const void *src, hipStream_t st, int
   if (h->twopass)
     HIP_TRY(reduce_classes_launch<T>((T *)dst, (const T *)src, (const T *)h->d_halo, h->d_p2arr, h->d_p2tiles,
                                      h->n_p2tiles, add, st));
-  HIP_TRY(orphan_launch<T>((T *)dst, (const T *)src, h->d_orphans, (uint32_t)P.orphans.size(), add, st));
+  else  // coloured mode has no pass 2: the dofs no cell touches get their own small kernel
+    HIP_TRY(orphan_launch<T>((T *)dst, (const T *)src, h->d_orphans, (uint32_t)P.orphans.size(), add, st));
   if (h->prof) h->prof_vmults++;
   return 0;
 }
