@@ -89,7 +89,10 @@ def main():
     ap.add_argument("--cells", type=int, default=54, help="cells per direction at N=1")
     ap.add_argument("--cpu-cells", type=int, default=0, help="cells per direction of the CPU sample (0: as --cells)")
     ap.add_argument("--float", action="store_true", help="BMOP_USE_FLOATS")
-    ap.add_argument("--mode", default="p2p", choices=["p2p", "pair", "allreduce"])
+    ap.add_argument("--mode", default="cxx", choices=["cxx", "p2p", "pair", "allreduce"],
+                    help="N > 1: exchange of the slab interface planes. cxx (default): the library's C++ path behind "
+                         "the C-ABI (mfgpu_vmult_dist: RCCL send/recv on a side stream, overlapped with pass 2); the "
+                         "others: the Python test double pymfgpu/parallel.py over torch.distributed")
     ap.add_argument("--no-cpu", action="store_true")
     ap.add_argument("--kernel", default="auto", choices=["auto", "pencils", "pencils_x", "planes"],
                     help="mfgpu_desc.kernel: cell-loop kernel family (measurements; the default is the library's choice)")
@@ -160,12 +163,52 @@ def main():
 
     dst = torch.full((N_loc,), 0.1, device=dev, dtype=tdt)  # bmop.cu:140
     src = torch.zeros(N_loc, device=dev, dtype=tdt)
-    exch = SlabExchange(mesh, rank, world, dev, tdt, args.mode) if world > 1 else None
     stream = torch.cuda.current_stream().cuda_stream
+    exch, cxx = None, None
+    if world > 1 and args.mode == "cxx":
+        # RCCL unique id from rank 0 to everybody (over the torch process group), then the library's own communicator
+        idt = torch.zeros(128, dtype=torch.uint8, device=dev)
+        if rank == 0:
+            idt.copy_(torch.frombuffer(bytearray(mf.dist_unique_id()), dtype=torch.uint8))
+        dist.broadcast(idt, 0)
+        try:
+            cxx = mf.Dist(mesh, rank, world, unique_id=bytes(idt.cpu().numpy().tobytes()))
+            cxx.attach(op)
+            failed = 0.0
+        except mf.MfgpuError as e:
+            print(f"[bench] rank {rank}: mfgpu_dist_create failed ({e}); falling back to --mode p2p", file=sys.stderr)
+            cxx, failed = None, 1.0
+        flag = torch.tensor([failed], device=dev)
+        dist.all_reduce(flag, op=dist.ReduceOp.MAX)
+        if flag.item() != 0.0:  # all ranks or none
+            cxx = None
+            args.mode = "p2p"
+            exch = SlabExchange(mesh, rank, world, dev, tdt, "p2p")
+    if cxx is not None:
+        # the first multi-GPU run is also the first run of the RCCL transport (no multi-GPU box during development):
+        # check one distributed apply against the dense all-reduce of the interface planes before anything is timed
+        chk = SlabExchange(mesh, rank, world, dev, tdt, "allreduce")
+        xs = torch.linspace(0.5, 1.5, N_loc, device=dev, dtype=tdt)
+        y1, y2 = torch.empty_like(xs), torch.empty_like(xs)
+        cxx.vmult(op, y1, xs, stream)
+        op.vmult(y2, xs, stream)
+        chk.exchange_add(y2)
+        torch.cuda.synchronize()
+        err = float((y1 - y2).norm() / y2.norm())
+        bad = torch.tensor([0.0 if err <= (1e-5 if args.float else 1e-12) else 1.0], device=dev)
+        dist.all_reduce(bad, op=dist.ReduceOp.MAX)
+        if bad.item() != 0.0:
+            raise SystemExit("mfgpu_vmult_dist disagrees with the all-reduce exchange of the interface planes")
+        del chk, xs, y1, y2
+    elif world > 1 and exch is None:
+        exch = SlabExchange(mesh, rank, world, dev, tdt, args.mode)
 
     def step():
         nonlocal dst, src
         dst, src = src, dst  # GpuVector::swap
+        if cxx is not None:
+            cxx.vmult(op, dst, src, stream)
+            return
         op.vmult(dst, src, stream)
         if exch is not None:
             exch.exchange_add(dst)

@@ -44,8 +44,10 @@ struct mfgpu_handle {
   // two-pass mode
   bool twopass = true;
   uint32_t *d_batch_nint = nullptr, *d_halo_off = nullptr;
-  uint32_t *d_p2arr = nullptr, *d_p2tiles = nullptr;  // pass 2, class-sorted form (mfgpu_pass2.hip)
-  uint32_t n_p2tiles = 0;
+  // pass 2, class-sorted form (mfgpu_pass2.hip), in two groups: [0] the priority dofs (mfgpu_dist: the slab's interface
+  // planes, reduced first so that their exchange overlaps the rest), [1] all others (everything without priorities)
+  uint32_t *d_p2arr[2] = {nullptr, nullptr}, *d_p2tiles[2] = {nullptr, nullptr};
+  uint32_t n_p2tiles[2] = {0, 0};
   void *d_halo = nullptr;
   unsigned long long *d_stamps = nullptr;  // diagnostic build only
   size_t lds = 0, device_bytes = 0;
@@ -102,6 +104,46 @@ int check_symmetrize(int n, std::vector<double> &S, std::vector<double> &Dt) {
         Dt[r * n + c] = 0.0;
       }
     }
+  return 0;
+}
+
+// pass-2 arrays from the plan: group 0 = the dofs listed in `priority` (may be empty), group 1 = the rest.  Pass 2 also
+// writes the dofs no cell touches (hanging dofs after substitution: dst = 0, or the identity row of a constrained one):
+// listed with ONE partial sum, a halo slot behind the batches' that is zero and stays zero.
+int upload_pass2(mfgpu_handle *h, const uint32_t *priority, uint32_t n_priority) {
+  const Plan &P = h->plan;
+  std::vector<uint8_t> prio(P.n_dofs, 0);
+  for (uint32_t i = 0; i < n_priority; ++i) {
+    if (priority[i] >= P.n_dofs) {
+      set_error("priority dof out of range");
+      return MFGPU_EINVAL;
+    }
+    prio[priority[i]] = 1;
+  }
+  std::vector<uint32_t> sd[2], so[2], si[2];
+  so[0].push_back(0);
+  so[1].push_back(0);
+  auto add = [&](uint32_t dof, const uint32_t *slots, uint32_t k) {
+    const int g = prio[dof & 0x7fffffffu] ? 0 : 1;
+    sd[g].push_back(dof);
+    si[g].insert(si[g].end(), slots, slots + k);
+    so[g].push_back((uint32_t)si[g].size());
+  };
+  for (size_t i = 0; i < P.sdofs.size(); ++i) add(P.sdofs[i], P.s_idx.data() + P.s_off[i], P.s_off[i + 1] - P.s_off[i]);
+  const uint32_t zero_slot = P.halo_off.empty() ? 0u : P.halo_off.back();
+  for (uint32_t orph : P.orphans) add(orph, &zero_slot, 1);
+  for (int g = 0; g < 2; ++g) {
+    hipFree(h->d_p2arr[g]);
+    hipFree(h->d_p2tiles[g]);
+    h->d_p2arr[g] = h->d_p2tiles[g] = nullptr;
+    std::vector<uint32_t> arr, tiles;
+    build_pass2_classes(sd[g], so[g], si[g], arr, tiles);
+    h->n_p2tiles[g] = (uint32_t)(tiles.size() / 4);
+    size_t acct = 0;
+    int rc;
+    if ((rc = dev_upload(&h->d_p2arr[g], arr.data(), arr.size() * 4, acct))) return rc;
+    if ((rc = dev_upload(&h->d_p2tiles[g], tiles.data(), tiles.size() * 4, acct))) return rc;
+  }
   return 0;
 }
 
@@ -195,20 +237,7 @@ int create_typed(mfgpu_handle *h, const mfgpu_desc &d) {
   if (h->twopass) {
     if ((rc = dev_upload(&h->d_batch_nint, P.batch_nint.data(), P.batch_nint.size() * 4, acct))) return rc;
     if ((rc = dev_upload(&h->d_halo_off, P.halo_off.data(), P.halo_off.size() * 4, acct))) return rc;
-    {
-      // pass 2 also writes the dofs no cell touches (hanging dofs after substitution: dst = 0, or the identity row of
-      // a constrained one): listed with ONE partial sum, a halo slot behind the batches' that is zero and stays zero
-      std::vector<uint32_t> sd(P.sdofs), so(P.s_off), si(P.s_idx), arr, tiles;
-      for (uint32_t orph : P.orphans) {
-        sd.push_back(orph);
-        si.push_back(P.halo_off.back());
-        so.push_back((uint32_t)si.size());
-      }
-      build_pass2_classes(sd, so, si, arr, tiles);
-      h->n_p2tiles = (uint32_t)(tiles.size() / 4);
-      if ((rc = dev_upload(&h->d_p2arr, arr.data(), arr.size() * 4, acct))) return rc;
-      if ((rc = dev_upload(&h->d_p2tiles, tiles.data(), tiles.size() * 4, acct))) return rc;
-    }
+    if ((rc = upload_pass2(h, nullptr, 0))) return rc;
     if (h->pk && (uint64_t)P.halo_off.back() >= (1ull << 29)) {
       set_error("halo buffer too large for 32-bit byte offsets");
       return MFGPU_EUNSUPPORTED;
@@ -344,8 +373,18 @@ int create_typed(mfgpu_handle *h, const mfgpu_desc &d) {
   return 0;
 }
 
+// one vmult in three phases: the cell loop; pass 2 of the priority dofs; pass 2 of the rest.  mfgpu_vmult runs them back
+// to back; mfgpu_vmult_dist_begin starts the exchange of the slab's interface planes between the last two.
 template <typename T>
-int vmult_typed(mfgpu_handle *h, void *dst, const void *src, hipStream_t st, int add) {
+int vmult_pass2(mfgpu_handle *h, int group, void *dst, const void *src, hipStream_t st, int add) {
+  if (h->twopass)
+    HIP_TRY(reduce_classes_launch<T>((T *)dst, (const T *)src, (const T *)h->d_halo, h->d_p2arr[group], h->d_p2tiles[group],
+                                     h->n_p2tiles[group], add, st));
+  return 0;
+}
+
+template <typename T>
+int vmult_main(mfgpu_handle *h, void *dst, const void *src, hipStream_t st, int add) {
   const Plan &P = h->plan;
   ApplyArgs<T> a;
   a.batch_cell_off = h->d_batch_cell_off;
@@ -415,13 +454,18 @@ int vmult_typed(mfgpu_handle *h, void *dst, const void *src, hipStream_t st, int
       h->ev_used += 2;
     }
   }
-  if (h->twopass)
-    HIP_TRY(reduce_classes_launch<T>((T *)dst, (const T *)src, (const T *)h->d_halo, h->d_p2arr, h->d_p2tiles,
-                                     h->n_p2tiles, add, st));
-  else  // coloured mode has no pass 2: the dofs no cell touches get their own small kernel
+  if (!h->twopass)  // coloured mode has no pass 2: the dofs no cell touches get their own small kernel
     HIP_TRY(orphan_launch<T>((T *)dst, (const T *)src, h->d_orphans, (uint32_t)P.orphans.size(), add, st));
   if (h->prof) h->prof_vmults++;
   return 0;
+}
+
+template <typename T>
+int vmult_typed(mfgpu_handle *h, void *dst, const void *src, hipStream_t st, int add) {
+  int rc = vmult_main<T>(h, dst, src, st, add);
+  if (!rc) rc = vmult_pass2<T>(h, 0, dst, src, st, add);
+  if (!rc) rc = vmult_pass2<T>(h, 1, dst, src, st, add);
+  return rc;
 }
 
 }  // namespace
@@ -491,6 +535,20 @@ int vec_reduce(int op, void *v, const void *x, const void *w, double a, size_t n
 }
 }  // namespace
 
+
+// ---- entry points of mfgpu_dist.hip (multi-GPU slab exchange) into the operator
+namespace mfgpu {
+int handle_number_type(const mfgpu_handle *h) { return h->number_type; }
+int handle_set_priority_dofs(mfgpu_handle *h, const uint32_t *ids, uint32_t n) {
+  return h->twopass ? upload_pass2(h, ids, n) : 0;
+}
+int handle_vmult_phase(mfgpu_handle *h, int phase, void *dst, const void *src, void *stream, int add) {
+  hipStream_t st = (hipStream_t)stream;
+  if (h->number_type == MFGPU_F64)
+    return phase == 0 ? vmult_main<double>(h, dst, src, st, add) : vmult_pass2<double>(h, phase - 1, dst, src, st, add);
+  return phase == 0 ? vmult_main<float>(h, dst, src, st, add) : vmult_pass2<float>(h, phase - 1, dst, src, st, add);
+}
+}  // namespace mfgpu
 
 extern "C" {
 
@@ -579,8 +637,10 @@ void mfgpu_destroy(mfgpu_handle *h) {
   hipFree(h->d_hnw);
   hipFree(h->d_batch_nint);
   hipFree(h->d_halo_off);
-  hipFree(h->d_p2arr);
-  hipFree(h->d_p2tiles);
+  for (int g = 0; g < 2; ++g) {
+    hipFree(h->d_p2arr[g]);
+    hipFree(h->d_p2tiles[g]);
+  }
   hipFree(h->d_halo);
   hipFree(h->d_stamps);
   for (hipEvent_t e : h->ev) hipEventDestroy(e);

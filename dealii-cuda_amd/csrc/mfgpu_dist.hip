@@ -1,0 +1,288 @@
+// Single-node multi-GPU mode behind the C-ABI: one process per GPU, cells sharded by z-slab, the partial sums on a
+// slab's two interface planes exchanged with the z-neighbours over RCCL (xGMI point-to-point links) after the
+// local cell loop.  The reference is single-GPU (no MPI / NCCL anywhere); this is new work
+// shaped by SURVEY.md 8e:
+//
+//   mfgpu_vmult_dist_begin   cell loop of the slab            (launch stream)
+//                            pass 2 of the INTERFACE dofs     (launch stream)   -> the planes hold the slab's sums
+//                            pack the planes                  (launch stream), event
+//                            grouped ncclSend / ncclRecv with both neighbours  (side stream, after the event)
+//                            pass 2 of all other dofs         (launch stream)   -- overlaps the exchange
+//   mfgpu_vmult_dist_end     wait for the exchange; dst[plane] += received, constrained rows excepted (identity
+//                            rows on both sides, laplace_operator_gpu.h:300-302)
+//
+// A slab shares dofs only with its two neighbours, so the exchange is two point-to-point transfers per rank, not a
+// collective over all ranks.  Transports: RCCL (ncclSend / ncclRecv on a communicator created from a unique id), or
+// IN-PROCESS (mfgpu_dist_connect_local: the neighbours are objects of the same process and the transfer is a device
+// copy) -- the second exists so that the whole path except the two RCCL calls runs in the single-GPU test suite.
+#include <hip/hip_runtime.h>
+#include <rccl/rccl.h>
+
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include "mfgpu_internal.h"
+
+using namespace mfgpu;
+
+#define HIP_TRY(expr)                                                                    \
+  do {                                                                                   \
+    hipError_t e_ = (expr);                                                              \
+    if (e_ != hipSuccess) {                                                              \
+      set_error(std::string(#expr) + ": " + hipGetErrorString(e_));                      \
+      return e_ == hipErrorOutOfMemory ? MFGPU_ENOMEM : MFGPU_EHIP;                      \
+    }                                                                                    \
+  } while (0)
+#define NCCL_TRY(expr)                                                                   \
+  do {                                                                                   \
+    ncclResult_t r_ = (expr);                                                            \
+    if (r_ != ncclSuccess) {                                                             \
+      set_error(std::string(#expr) + ": " + ncclGetErrorString(r_));                     \
+      return MFGPU_EHIP;                                                                 \
+    }                                                                                    \
+  } while (0)
+
+struct mfgpu_dist {
+  int rank = 0, world = 1, number_type = MFGPU_F64;
+  ncclComm_t comm = nullptr;            // RCCL transport, or
+  mfgpu_dist *local_peer[2] = {};       // in-process transport: the lower / upper neighbour's object
+  uint32_t n_if[2] = {0, 0};            // interface dofs on the lower / upper plane
+  std::vector<uint32_t> ids[2];         // their local dof ids (host copy: priority dofs of the operator)
+  uint32_t *d_ids[2] = {};              // device copy
+  uint8_t *d_free[2] = {};              // 1: summed with the neighbour, 0: constrained (identity row)
+  void *d_send[2] = {}, *d_recv[2] = {};
+  hipStream_t side = nullptr;
+  hipEvent_t ev_packed = nullptr, ev_done = nullptr;
+  bool in_flight = false;
+};
+
+namespace {
+
+template <typename T>
+__global__ void pack_kernel(T *out, const T *vec, const uint32_t *ids, uint32_t n) {
+  const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) out[i] = vec[ids[i]];
+}
+template <typename T>
+__global__ void add_kernel(T *vec, const T *in, const uint32_t *ids, const uint8_t *free_, uint32_t n) {
+  const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n && free_[i]) vec[ids[i]] += in[i];
+}
+size_t esize(int nt) { return nt == MFGPU_F32 ? 4 : 8; }
+
+int pack_planes(mfgpu_dist *d, const void *vec, hipStream_t st) {
+  for (int w = 0; w < 2; ++w) {
+    if (!d->n_if[w]) continue;
+    const unsigned grid = (d->n_if[w] + 255) / 256;
+    if (d->number_type == MFGPU_F64)
+      hipLaunchKernelGGL(pack_kernel<double>, dim3(grid), dim3(256), 0, st, (double *)d->d_send[w], (const double *)vec,
+                         d->d_ids[w], d->n_if[w]);
+    else
+      hipLaunchKernelGGL(pack_kernel<float>, dim3(grid), dim3(256), 0, st, (float *)d->d_send[w], (const float *)vec,
+                         d->d_ids[w], d->n_if[w]);
+    HIP_TRY(hipGetLastError());
+  }
+  return 0;
+}
+
+// grouped send / recv with both neighbours on the side stream, behind the pack
+int start_exchange(mfgpu_dist *d, hipStream_t st) {
+  HIP_TRY(hipEventRecord(d->ev_packed, st));
+  d->in_flight = true;
+  if (!d->comm) return 0;  // in-process transport: the copies happen in finish_exchange, when every peer has packed
+  HIP_TRY(hipStreamWaitEvent(d->side, d->ev_packed, 0));
+  const ncclDataType_t dt = d->number_type == MFGPU_F64 ? ncclDouble : ncclFloat;
+  NCCL_TRY(ncclGroupStart());
+  for (int w = 0; w < 2; ++w) {
+    if (!d->n_if[w]) continue;
+    const int peer = w == 0 ? d->rank - 1 : d->rank + 1;
+    NCCL_TRY(ncclSend(d->d_send[w], d->n_if[w], dt, peer, d->comm, d->side));
+    NCCL_TRY(ncclRecv(d->d_recv[w], d->n_if[w], dt, peer, d->comm, d->side));
+  }
+  NCCL_TRY(ncclGroupEnd());
+  HIP_TRY(hipEventRecord(d->ev_done, d->side));
+  return 0;
+}
+
+int finish_exchange(mfgpu_dist *d, void *vec, hipStream_t st) {
+  if (!d->in_flight) {
+    set_error("mfgpu_vmult_dist_end without a matching _begin");
+    return MFGPU_EINVAL;
+  }
+  d->in_flight = false;
+  if (d->comm) {
+    HIP_TRY(hipStreamWaitEvent(st, d->ev_done, 0));
+  } else {
+    for (int w = 0; w < 2; ++w) {
+      if (!d->n_if[w]) continue;
+      mfgpu_dist *p = d->local_peer[w];
+      if (!p || p->n_if[1 - w] != d->n_if[w]) {
+        set_error("in-process transport: neighbour not connected (mfgpu_dist_connect_local)");
+        return MFGPU_EINVAL;
+      }
+      // my lower plane is the neighbour's upper plane and vice versa
+      HIP_TRY(hipStreamWaitEvent(st, p->ev_packed, 0));
+      HIP_TRY(hipMemcpyAsync(d->d_recv[w], p->d_send[1 - w], (size_t)d->n_if[w] * esize(d->number_type),
+                             hipMemcpyDeviceToDevice, st));
+    }
+  }
+  for (int w = 0; w < 2; ++w) {
+    if (!d->n_if[w]) continue;
+    const unsigned grid = (d->n_if[w] + 255) / 256;
+    if (d->number_type == MFGPU_F64)
+      hipLaunchKernelGGL(add_kernel<double>, dim3(grid), dim3(256), 0, st, (double *)vec, (const double *)d->d_recv[w],
+                         d->d_ids[w], d->d_free[w], d->n_if[w]);
+    else
+      hipLaunchKernelGGL(add_kernel<float>, dim3(grid), dim3(256), 0, st, (float *)vec, (const float *)d->d_recv[w],
+                         d->d_ids[w], d->d_free[w], d->n_if[w]);
+    HIP_TRY(hipGetLastError());
+  }
+  return 0;
+}
+
+}  // namespace
+
+extern "C" {
+
+int mfgpu_dist_unique_id(void *id128) {
+  if (!id128) return MFGPU_EINVAL;
+  static_assert(sizeof(ncclUniqueId) == 128, "ncclUniqueId is 128 bytes");
+  ncclUniqueId id;
+  NCCL_TRY(ncclGetUniqueId(&id));
+  std::memcpy(id128, &id, sizeof(id));
+  return 0;
+}
+
+int mfgpu_dist_create(const void *id128, int rank, int world, const uint32_t *lower_ids, uint32_t n_lower,
+                      const uint32_t *upper_ids, uint32_t n_upper, const uint32_t *constrained, uint32_t n_constrained,
+                      uint32_t n_dofs, int number_type, mfgpu_dist **out) {
+  if (!out || world < 1 || rank < 0 || rank >= world || (n_lower && !lower_ids) || (n_upper && !upper_ids) ||
+      (n_constrained && !constrained) || (number_type != MFGPU_F64 && number_type != MFGPU_F32)) {
+    set_error("mfgpu_dist_create: bad argument");
+    return MFGPU_EINVAL;
+  }
+  if ((rank == 0 && n_lower) || (rank == world - 1 && n_upper)) {
+    set_error("mfgpu_dist_create: the first / last slab has no lower / upper neighbour");
+    return MFGPU_EINVAL;
+  }
+  mfgpu_dist *d = new mfgpu_dist();
+  d->rank = rank;
+  d->world = world;
+  d->number_type = number_type;
+  std::vector<uint8_t> con(n_dofs, 0);
+  for (uint32_t i = 0; i < n_constrained; ++i)
+    if (constrained[i] < n_dofs) con[constrained[i]] = 1;
+  const uint32_t *src_ids[2] = {lower_ids, upper_ids};
+  const uint32_t cnt[2] = {n_lower, n_upper};
+  auto fail = [&](int rc) {
+    mfgpu_dist_destroy(d);
+    return rc;
+  };
+  for (int w = 0; w < 2; ++w) {
+    d->n_if[w] = cnt[w];
+    if (!cnt[w]) continue;
+    d->ids[w].assign(src_ids[w], src_ids[w] + cnt[w]);
+    std::vector<uint8_t> fr(cnt[w]);
+    for (uint32_t i = 0; i < cnt[w]; ++i) {
+      if (src_ids[w][i] >= n_dofs) {
+        set_error("mfgpu_dist_create: interface dof out of range");
+        return fail(MFGPU_EINVAL);
+      }
+      fr[i] = con[src_ids[w][i]] ? 0 : 1;
+    }
+    const size_t vb = (size_t)cnt[w] * esize(number_type);
+    if (hipMalloc((void **)&d->d_ids[w], (size_t)cnt[w] * 4) != hipSuccess || hipMalloc((void **)&d->d_free[w], cnt[w]) != hipSuccess ||
+        hipMalloc(&d->d_send[w], vb) != hipSuccess || hipMalloc(&d->d_recv[w], vb) != hipSuccess ||
+        hipMemcpy(d->d_ids[w], src_ids[w], (size_t)cnt[w] * 4, hipMemcpyHostToDevice) != hipSuccess ||
+        hipMemcpy(d->d_free[w], fr.data(), cnt[w], hipMemcpyHostToDevice) != hipSuccess) {
+      set_error("mfgpu_dist_create: device allocation failed");
+      return fail(MFGPU_ENOMEM);
+    }
+  }
+  if (hipStreamCreateWithFlags(&d->side, hipStreamNonBlocking) != hipSuccess ||
+      hipEventCreateWithFlags(&d->ev_packed, hipEventDisableTiming) != hipSuccess ||
+      hipEventCreateWithFlags(&d->ev_done, hipEventDisableTiming) != hipSuccess) {
+    set_error("mfgpu_dist_create: stream / event creation failed");
+    return fail(MFGPU_EHIP);
+  }
+  if (id128 && world > 1) {
+    ncclUniqueId id;
+    std::memcpy(&id, id128, sizeof(id));
+    ncclResult_t r = ncclCommInitRank(&d->comm, world, id, rank);
+    if (r != ncclSuccess) {
+      set_error(std::string("ncclCommInitRank: ") + ncclGetErrorString(r));
+      d->comm = nullptr;
+      return fail(MFGPU_EHIP);
+    }
+  }
+  *out = d;
+  return 0;
+}
+
+int mfgpu_dist_connect_local(mfgpu_dist *lower_rank, mfgpu_dist *upper_rank) {
+  if (!lower_rank || !upper_rank || lower_rank->comm || upper_rank->comm ||
+      lower_rank->n_if[1] != upper_rank->n_if[0] || lower_rank->number_type != upper_rank->number_type) {
+    set_error("mfgpu_dist_connect_local: not two adjacent in-process slabs");
+    return MFGPU_EINVAL;
+  }
+  lower_rank->local_peer[1] = upper_rank;
+  upper_rank->local_peer[0] = lower_rank;
+  return 0;
+}
+
+int mfgpu_dist_attach(mfgpu_dist *d, mfgpu_handle *h) {
+  if (!d || !h || handle_number_type(h) != d->number_type) {
+    set_error("mfgpu_dist_attach: null argument or number type mismatch");
+    return MFGPU_EINVAL;
+  }
+  std::vector<uint32_t> all(d->ids[0]);
+  all.insert(all.end(), d->ids[1].begin(), d->ids[1].end());
+  return handle_set_priority_dofs(h, all.data(), (uint32_t)all.size());
+}
+
+int mfgpu_vmult_dist_begin(mfgpu_handle *h, mfgpu_dist *d, void *dst, const void *src, void *stream) {
+  if (!h || !d || !dst || !src || dst == src) {
+    set_error("mfgpu_vmult_dist_begin: null or aliasing argument");
+    return MFGPU_EINVAL;
+  }
+  hipStream_t st = (hipStream_t)stream;
+  int rc = handle_vmult_phase(h, 0, dst, src, stream, 0);
+  if (!rc) rc = handle_vmult_phase(h, 1, dst, src, stream, 0);  // the interface planes are complete
+  if (!rc) rc = pack_planes(d, dst, st);
+  if (!rc) rc = start_exchange(d, st);
+  if (!rc) rc = handle_vmult_phase(h, 2, dst, src, stream, 0);  // overlaps the exchange
+  return rc;
+}
+
+int mfgpu_vmult_dist_end(mfgpu_handle *h, mfgpu_dist *d, void *dst, void *stream) {
+  if (!h || !d || !dst) {
+    set_error("mfgpu_vmult_dist_end: null argument");
+    return MFGPU_EINVAL;
+  }
+  return finish_exchange(d, dst, (hipStream_t)stream);
+}
+
+int mfgpu_vmult_dist(mfgpu_handle *h, mfgpu_dist *d, void *dst, const void *src, void *stream) {
+  int rc = mfgpu_vmult_dist_begin(h, d, dst, src, stream);
+  if (!rc) rc = mfgpu_vmult_dist_end(h, d, dst, stream);
+  return rc;
+}
+
+void mfgpu_dist_destroy(mfgpu_dist *d) {
+  if (!d) return;
+  if (d->comm) ncclCommDestroy(d->comm);
+  for (int w = 0; w < 2; ++w) {
+    hipFree(d->d_ids[w]);
+    hipFree(d->d_free[w]);
+    hipFree(d->d_send[w]);
+    hipFree(d->d_recv[w]);
+    if (d->local_peer[w]) d->local_peer[w]->local_peer[1 - w] = nullptr;
+  }
+  if (d->side) hipStreamDestroy(d->side);
+  if (d->ev_packed) hipEventDestroy(d->ev_packed);
+  if (d->ev_done) hipEventDestroy(d->ev_done);
+  delete d;
+}
+
+}  // extern "C"

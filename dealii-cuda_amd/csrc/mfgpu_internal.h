@@ -103,6 +103,12 @@ int choose_kernel_and_plan(const mfgpu_desc &d, KernelChoice &kc, Plan &plan);
 int derive_tables(int n, const double *shape_values, const double *shape_gradients,
                   std::vector<double> &S, std::vector<double> &Dt);
 
+// entry points of mfgpu_dist.hip into the operator (mfgpu_api.hip): phase 0 = cell loop, 1 = pass 2 of the priority
+// dofs, 2 = pass 2 of the rest
+int handle_number_type(const mfgpu_handle *h);
+int handle_set_priority_dofs(mfgpu_handle *h, const uint32_t *ids, uint32_t n);
+int handle_vmult_phase(mfgpu_handle *h, int phase, void *dst, const void *src, void *stream, int add);
+
 }  // namespace mfgpu
 
 struct mfgpu_plan {

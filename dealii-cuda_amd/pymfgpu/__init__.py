@@ -49,6 +49,8 @@ SYMBOLS = [
     "mfgpu_device_synchronize", "mfgpu_device_memory_info", "mfgpu_mesh_create_uniform", "mfgpu_mesh_create_adaptive", "mfgpu_mesh_create_from_leaves",
     "mfgpu_mesh_cell_levels", "mfgpu_mesh_destroy",
     "mfgpu_mesh_desc", "mfgpu_mesh_dof_coords", "mfgpu_mesh_interface_dofs",
+    "mfgpu_dist_unique_id", "mfgpu_dist_create", "mfgpu_dist_connect_local", "mfgpu_dist_attach",
+    "mfgpu_vmult_dist_begin", "mfgpu_vmult_dist_end", "mfgpu_vmult_dist", "mfgpu_dist_destroy",
 ]
 
 _lib = None
@@ -468,3 +470,58 @@ def device_memory_info():
     f, t = C.c_size_t(), C.c_size_t()
     _check(lib().mfgpu_device_memory_info(C.byref(f), C.byref(t)))
     return f.value, t.value
+
+
+def dist_unique_id() -> bytes:
+    """rank 0: the 128-byte RCCL unique id every rank passes to Dist (mfgpu_dist_unique_id)"""
+    buf = C.create_string_buffer(128)
+    _check(lib().mfgpu_dist_unique_id(buf))
+    return buf.raw
+
+
+class Dist:
+    """mfgpu_dist: exchange of a z-slab's interface planes with its two neighbours (include/mfgpu.h).
+    unique_id = the bytes of dist_unique_id() (RCCL transport, collective over all ranks), or None (in-process
+    transport: connect neighbours with connect_local)."""
+
+    def __init__(self, mesh: "Mesh", rank: int, world: int, unique_id=None):
+        lo = np.ascontiguousarray(mesh.interface_dofs(0), dtype=np.uint32)
+        up = np.ascontiguousarray(mesh.interface_dofs(1), dtype=np.uint32)
+        con = np.ascontiguousarray(mesh.arrays()["constrained_dofs"], dtype=np.uint32)
+        self._keep = (lo, up, con)
+        self.number_type = mesh.desc.number_type
+        d = C.c_void_p()
+        L = lib()
+        L.mfgpu_dist_create.argtypes = [C.c_char_p, C.c_int, C.c_int, C.c_void_p, C.c_uint32, C.c_void_p, C.c_uint32,
+                                        C.c_void_p, C.c_uint32, C.c_uint32, C.c_int, C.c_void_p]
+        _check(L.mfgpu_dist_create(unique_id, rank, world, lo.ctypes.data if lo.size else None, lo.size,
+                                   up.ctypes.data if up.size else None, up.size, con.ctypes.data if con.size else None,
+                                   con.size, mesh.n_dofs, self.number_type, C.byref(d)))
+        self._d = d
+        for f in ("mfgpu_dist_connect_local", "mfgpu_dist_attach"):
+            getattr(L, f).argtypes = [C.c_void_p, C.c_void_p]
+        L.mfgpu_vmult_dist_begin.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
+        L.mfgpu_vmult_dist.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
+        L.mfgpu_vmult_dist_end.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
+        L.mfgpu_dist_destroy.argtypes = [C.c_void_p]
+
+    def __del__(self):
+        if getattr(self, "_d", None) and _lib is not None:
+            _lib.mfgpu_dist_destroy(self._d)
+            self._d = None
+
+    def connect_local(self, upper: "Dist"):
+        """in-process transport: `upper` is the slab above this one"""
+        _check(lib().mfgpu_dist_connect_local(self._d, upper._d))
+
+    def attach(self, op: "Operator"):
+        _check(lib().mfgpu_dist_attach(self._d, op._h))
+
+    def vmult_begin(self, op, dst, src, stream=None):
+        _check(lib().mfgpu_vmult_dist_begin(op._h, self._d, _ptr(dst), _ptr(src), stream))
+
+    def vmult_end(self, op, dst, stream=None):
+        _check(lib().mfgpu_vmult_dist_end(op._h, self._d, _ptr(dst), stream))
+
+    def vmult(self, op, dst, src, stream=None):
+        _check(lib().mfgpu_vmult_dist(op._h, self._d, _ptr(dst), _ptr(src), stream))

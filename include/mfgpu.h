@@ -191,6 +191,33 @@ int mfgpu_device_synchronize(void);
  * mfgpu_destroy / mfgpu_vec_free return everything mfgpu_create / mfgpu_vec_alloc took              */
 int mfgpu_device_memory_info(size_t *free_bytes, size_t *total_bytes); /* bmop.cu:148 */
 
+/* ---- single-node multi-GPU mode (no reference counterpart: the reference is single-GPU) --------
+ * One process per GPU; the mesh is cut into z-slabs (mfgpu_mesh_create_uniform's slab arguments), each rank owns the
+ * vector entries of its slab including both interface planes.  After the slab's cell loop an interface plane holds
+ * only the rank's own cells' contributions; the exchange adds the neighbour's, leaving the full sum on both sharers
+ * (constrained rows are identity rows on both sides and are not summed).  Transport: RCCL point-to-point send / recv
+ * with the two z-neighbours on a side stream, overlapped with pass 2 of the slab's other dofs.                       */
+typedef struct mfgpu_dist mfgpu_dist;
+/* rank 0: a 128-byte RCCL unique id to hand to every rank (any out-of-band channel) */
+int mfgpu_dist_unique_id(void *id128);
+/* collective over all ranks when id128 != NULL and world > 1 (ncclCommInitRank on the current HIP device).
+ * lower_ids / upper_ids: local dof ids of the slab's lower / upper interface plane in the order both neighbours
+ * agree on (mfgpu_mesh_interface_dofs); constrained: the description's constrained_dofs.  id128 == NULL: no RCCL
+ * communicator; the neighbours are connected in-process with mfgpu_dist_connect_local (tests).                    */
+int mfgpu_dist_create(const void *id128, int rank, int world, const uint32_t *lower_ids, uint32_t n_lower,
+                      const uint32_t *upper_ids, uint32_t n_upper, const uint32_t *constrained_dofs,
+                      uint32_t n_constrained, uint32_t n_dofs, int number_type, mfgpu_dist **out);
+int mfgpu_dist_connect_local(mfgpu_dist *lower_rank, mfgpu_dist *upper_rank);
+/* tells the operator which dofs the exchange needs first (re-orders its pass 2); once per (operator, dist) pair */
+int mfgpu_dist_attach(mfgpu_dist *d, mfgpu_handle *h);
+/* dst = A src on the slab, then the exchange.  _begin: cell loop, pass 2 of the interface dofs, start of the
+ * transfers (side stream), pass 2 of the rest; _end: wait for the transfers, add.  mfgpu_vmult_dist = both (RCCL
+ * transport or world == 1; with the in-process transport call _begin on every slab before any _end).             */
+int mfgpu_vmult_dist_begin(mfgpu_handle *h, mfgpu_dist *d, void *dst_dev, const void *src_dev, void *stream);
+int mfgpu_vmult_dist_end(mfgpu_handle *h, mfgpu_dist *d, void *dst_dev, void *stream);
+int mfgpu_vmult_dist(mfgpu_handle *h, mfgpu_dist *d, void *dst_dev, const void *src_dev, void *stream);
+void mfgpu_dist_destroy(mfgpu_dist *d);
+
 /* ---- deal.II stand-in for the setup side (host only) --------------------------------------
  * Produces what Triangulation + DoFHandler + ConstraintMatrix + FEValues + ShapeInfo hand to
  * MatrixFreeGpu::reinit, for the meshes bmop uses (bmop_common.h:108-120).                    */

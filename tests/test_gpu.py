@@ -397,6 +397,55 @@ def test_slab_decomposition_with_the_gpu_operator(p, n, world):
         x = acc
 
 
+@pytest.mark.parametrize("p,n,world", [(4, 6, 2), (4, 7, 3), (2, 8, 4), (3, 6, 2)])
+@pytest.mark.parametrize("nt", [mf.F64, mf.F32])
+def test_cxx_slab_exchange_in_process(p, n, world, nt):
+    """the C++ multi-GPU path behind the C-ABI (mfgpu_dist: priority pass 2 of the interface planes, pack, transfer,
+    masked add, overlap with the rest of pass 2) on ONE GPU: every slab is an operator + mfgpu_dist of this process,
+    connected by the in-process transport -- everything but the two RCCL calls of the real transport.  Three chained
+    distributed applies against the single-domain oracle."""
+    from pymfgpu.parallel import slab_ranges
+
+    full = mf.Mesh.uniform(3, p, n)
+    od = oracle_desc_from_mesh(full, dtype=np.float64)
+    key = {tuple(np.round(c, 9)): i for i, c in enumerate(full.dof_coords())}
+    slabs = []
+    for r, (zb, ze) in enumerate(slab_ranges(n, world)):
+        mesh = mf.Mesh.uniform(3, p, n, slab=(zb, ze), number_type=nt)
+        gi = np.array([key[tuple(np.round(c, 9))] for c in mesh.dof_coords()])
+        op = mf.Operator(mesh.desc, mesh)
+        dist = mf.Dist(mesh, r, world)
+        dist.attach(op)
+        a, b = mf.DeviceVector(mesh.n_dofs, nt), mf.DeviceVector(mesh.n_dofs, nt)
+        slabs.append(dict(mesh=mesh, op=op, dist=dist, gi=gi, a=a, b=b))
+    for lo, up in zip(slabs, slabs[1:]):
+        lo["dist"].connect_local(up["dist"])
+    fx = full.dof_coords()
+    x = (np.sin(3 * fx[:, 0]) + fx[:, 1] ** 2 - np.cos(2 * fx[:, 2]) * fx[:, 0]).astype(mf.np_dtype(nt)).astype(np.float64)
+    for s in slabs:
+        s["a"].from_host(x[s["gi"]])
+    ref = x
+    for it in range(3):
+        for s in slabs:
+            s["dist"].vmult_begin(s["op"], s["b"], s["a"])
+        for s in slabs:
+            s["dist"].vmult_end(s["op"], s["b"])
+        mf.synchronize()
+        ref = o.vmult(od, ref)
+        for s in slabs:
+            assert rel(s["b"].to_host(), ref[s["gi"]]) <= TOL[nt] * 100 ** it
+            s["a"], s["b"] = s["b"], s["a"]
+    # one slab, no neighbours: the distributed entry point is the plain vmult
+    mesh = mf.Mesh.uniform(3, p, n, number_type=nt)
+    op, dist = mf.Operator(mesh.desc, mesh), mf.Dist(mesh, 0, 1)
+    dist.attach(op)
+    a, b = mf.DeviceVector(mesh.n_dofs, nt), mf.DeviceVector(mesh.n_dofs, nt)
+    a.from_host(x)
+    dist.vmult(op, b, a)
+    mf.synchronize()
+    assert rel(b.to_host(), o.vmult(od, x)) <= TOL[nt]
+
+
 def test_create_destroy_returns_all_device_memory():
     """mfgpu_destroy / mfgpu_vec_free give back everything mfgpu_create / mfgpu_vec_alloc / the first vmult,
     diagonal and reduction took: repeated set-up and tear-down of operators of every kernel family must not
