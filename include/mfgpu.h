@@ -14,7 +14,9 @@
  * exception crosses the boundary; the reference throws dealii::ExcMessage,
  * cuda_utils.cuh:15-25); mfgpu_last_error() gives the message of the calling thread's
  * last failure.  Handles are independent (no process-global shape tables, unlike
- * matrix_free_gpu.h:45-48), thread-compatible, not thread-safe per handle.
+ * matrix_free_gpu.h:45-48), thread-compatible, not thread-safe per handle.  All calls on ONE handle must be ordered on
+ * a single stream (or serialised by the caller with events): every vmult uses the handle's halo buffer, so two
+ * vmults of one handle in flight on different streams race on it.
  * `stream` arguments are hipStream_t passed as void* (NULL = default stream).
  */
 #ifndef MFGPU_H

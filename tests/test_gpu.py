@@ -318,6 +318,48 @@ def test_adaptive_mesh_both_cell_loop_kernels(p, nref, xk):
     assert rel(gpu_vmult(op, x, y0=y0), o.vmult_add(od, y0, x)) <= 1e-12
 
 
+@pytest.mark.parametrize("p,nref", [(4, 4), (4, 5), (2, 5), (3, 5)])
+@pytest.mark.parametrize("kern", [mf.KERNEL_AUTO, mf.KERNEL_PENCILS_X, mf.KERNEL_PENCILS],
+                         ids=["auto", "apply_batches_x", "apply_batches"])
+def test_adaptive_mesh_multi_chunk_batches(p, nref, kern):
+    """hanging-node batches of several chunks of cells (max_cells_per_batch = 64: the production size on large
+    meshes) in every kernel family that handles them, against the oracle"""
+    mesh = mf.Mesh.adaptive(3, p, nref)
+    od = oracle_desc_from_mesh(mesh, dtype=np.float64)
+    mesh.desc.kernel = kern
+    mesh.desc.max_cells_per_batch = 64
+    op = mf.Operator(mesh.desc, mesh)
+    assert op.plan_stats()["max_batch_cells"] > 256 // (p + 1) ** 2
+    rng = np.random.default_rng(p + nref)
+    x, y0 = rng.standard_normal(mesh.n_dofs), rng.standard_normal(mesh.n_dofs)
+    assert rel(gpu_vmult(op, x), o.vmult(od, x)) <= 1e-12
+    assert rel(gpu_vmult(op, x, y0=y0), o.vmult_add(od, y0, x)) <= 1e-12
+
+
+def test_c5_full_size_properties():
+    """BASELINE configs[4] at full size (p = 6, 3D, 36^3 cells, 217^3 dofs): linearity, symmetry, identity rows,
+    constants in the kernel -- the size-independent properties of test_full_size_properties"""
+    mesh = mf.Mesh.uniform(3, 6, 36)
+    N = mesh.n_dofs
+    assert N == 217 ** 3
+    op = mf.Operator(mesh.desc, mesh)
+    con = mesh.arrays()["constrained_dofs"]
+    rng = np.random.default_rng(6)
+    u, v = rng.standard_normal(N), rng.standard_normal(N)
+    u[con] = 0
+    v[con] = 0
+    Au, Av = gpu_vmult(op, u), gpu_vmult(op, v)
+    assert np.abs(Au[con]).max() == 0.0                           # identity rows
+    assert abs(v @ Au - u @ Av) <= 1e-11 * abs(v @ Au) and u @ Au > 0
+    assert rel(gpu_vmult(op, 0.3 * u - 1.7 * v), 0.3 * Au - 1.7 * Av) <= 1e-12
+    y = gpu_vmult(op, np.ones(N))
+    g = 217
+    idx = np.arange(N)
+    ix, iy, iz = idx % g, (idx // g) % g, idx // (g * g)
+    deep = (ix >= 7) & (ix <= g - 8) & (iy >= 7) & (iy <= g - 8) & (iz >= 7) & (iz <= g - 8)
+    assert np.abs(y[deep]).max() <= 1e-10 * np.abs(y).max()
+
+
 def test_adaptive_float():
     mesh = mf.Mesh.adaptive(3, 4, 4, number_type=mf.F32)
     od = oracle_desc_from_mesh(mesh, dtype=np.float64)

@@ -31,6 +31,20 @@ def test_general_jacobian_vmult_matches_oracle(p, n, nt, tol):
     assert rel(gpu_vmult(op, x, nt, y0=y0), o.vmult_add(od, y0, x)) <= tol
 
 
+@pytest.mark.parametrize("p,n,cells", [(2, 8, 64), (4, 6, 27), (3, 6, 40)])
+def test_general_jacobian_multi_cell_batches(p, n, cells):
+    """batches of several chunks of cells (the default on large meshes; small meshes default to one cell per batch)"""
+    od = deformed_oracle_desc(p, n, seed=p)
+    desc, keep = desc_from_oracle(od, max_cells_per_batch=cells)
+    op = mf.Operator(desc, keep)
+    st = op.plan_stats()
+    assert op.kernel_name() == "apply_batches_g" and st["n_batches"] >= 2 and st["max_batch_cells"] > 256 // (p + 1) ** 2
+    rng = np.random.default_rng(11)
+    x, y0 = rng.standard_normal(od.n_dofs), rng.standard_normal(od.n_dofs)
+    assert rel(gpu_vmult(op, x), o.vmult(od, x)) <= 1e-12
+    assert rel(gpu_vmult(op, x, y0=y0), o.vmult_add(od, y0, x)) <= 1e-12
+
+
 def test_general_jacobian_against_assembled_matrix_and_symmetry():
     od = deformed_oracle_desc(3, 3, eps=0.2, seed=3)
     desc, keep = desc_from_oracle(od)
