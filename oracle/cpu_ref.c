@@ -137,7 +137,10 @@ INL void cells_apply_v(const int n, const double *Se, const double *Ge, const do
   }
 }
 
+/* The library is built in one container and run on another host: no -march=native.  The hot loops are cloned for
+ * AVX-512, AVX2 and the baseline ISA and dispatched at load time (GCC function multiversioning). */
 #define DEF_COLOUR_LOOP(N)                                                                                    \
+  __attribute__((target_clones("avx512f", "avx2", "default")))                                 \
   static void colour_loop_##N(const double *Se, const double *Ge, const double *S, const double *G,             \
                               const uint32_t *l2g, const double *coef, const double *jxw, const double *j0,   \
                               const uint32_t *cell_order, int64_t kb, int64_t ke, double *dst, const double *src) { \

@@ -30,4 +30,5 @@ def test_cpu_ref_protocol_golden():
     ref = cpu_ref.CpuRef(od, cpu_ref.structured_cell_colors([32, 32]))
     for k in (1, 2, 3):
         y = ref.bmop(k)
-        assert np.linalg.norm(y - g[f"prot{k}"]) <= 1e-12 * np.linalg.norm(g[f"prot{k}"])
+        # chained applies of the un-normalised operator amplify rounding differences by ||A|| ~ 100 per apply
+        assert np.linalg.norm(y - g[f"prot{k}"]) <= 1e-12 * 100 ** (k - 1) * np.linalg.norm(g[f"prot{k}"])
