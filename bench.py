@@ -96,6 +96,8 @@ def main():
     ap.add_argument("--no-cpu", action="store_true")
     ap.add_argument("--kernel", default="auto", choices=["auto", "pencils", "pencils_x", "planes"],
                     help="mfgpu_desc.kernel: cell-loop kernel family (measurements; the default is the library's choice)")
+    ap.add_argument("--segments", type=int, default=0,
+                    help="mfgpu_desc.cell_loop_segments (0 = the library's choice, 1 = no overlap of pass 2 with the cell loop)")
     ap.add_argument("--batch-cells", type=int, default=0)
     ap.add_argument("--batch-dofs", type=int, default=0)
     ap.add_argument("--colored", action="store_true", help="coloured-scatter mode instead of two-pass")
@@ -133,6 +135,7 @@ def main():
         mesh = mf.Mesh.uniform(3, p, n_glob, slab=(zb, ze), number_type=nt)
     mesh.desc.max_cells_per_batch = args.batch_cells
     mesh.desc.max_dofs_per_batch = args.batch_dofs
+    mesh.desc.cell_loop_segments = args.segments
     mesh.desc.kernel = {"auto": mf.KERNEL_AUTO, "pencils": mf.KERNEL_PENCILS, "pencils_x": mf.KERNEL_PENCILS_X,
                         "planes": mf.KERNEL_PLANES}[args.kernel]
     if args.colored:

@@ -1,6 +1,7 @@
 // C-ABI entry points (include/mfgpu.h): handle life cycle, vmult / vmult_add, GpuVector pieces.
 #include <hip/hip_runtime.h>
 
+#include <algorithm>
 #include <cmath>
 #include <cstdlib>
 #include <cstring>
@@ -44,10 +45,19 @@ struct mfgpu_handle {
   // two-pass mode
   bool twopass = true;
   uint32_t *d_batch_nint = nullptr, *d_halo_off = nullptr;
-  // pass 2, class-sorted form (mfgpu_pass2.hip), in two groups: [0] the priority dofs (mfgpu_dist: the slab's interface
-  // planes, reduced first so that their exchange overlaps the rest), [1] all others (everything without priorities)
-  uint32_t *d_p2arr[2] = {nullptr, nullptr}, *d_p2tiles[2] = {nullptr, nullptr};
-  uint32_t n_p2tiles[2] = {0, 0};
+  // The cell loop runs in SEGMENTS of consecutive batches, one launch each (seg_end[s] = one past the segment's last
+  // batch).  Pass 2, class-sorted form (mfgpu_pass2.hip), in 1 + n_segments groups: [0] the priority dofs (mfgpu_dist:
+  // the slab's interface planes, reduced first after the whole cell loop so that their exchange overlaps the rest),
+  // [1 + s] the other dofs whose LAST toucher batch lies in segment s.  Group 1 + s needs segments 0..s only, so for
+  // s < last it runs on the handle's side stream while the next segment's cells are computed (a latency-bound kernel
+  // next to an issue-bound one); the last group and the priority group run on the caller's stream.
+  std::vector<uint32_t> seg_end;
+  std::vector<uint32_t *> d_p2arr, d_p2tiles;
+  std::vector<uint32_t> n_p2tiles;
+  hipStream_t side = nullptr;
+  std::vector<hipEvent_t> ev_seg;  // [s]: segment s done (recorded on the caller's stream)
+  hipEvent_t ev_side = nullptr;    // the side stream's pass-2 launches of this vmult done
+  bool side_pending = false;       // the caller's stream has not joined the side stream yet
   void *d_halo = nullptr;
   unsigned long long *d_stamps = nullptr;  // diagnostic build only
   size_t lds = 0, device_bytes = 0;
@@ -120,22 +130,35 @@ int upload_pass2(mfgpu_handle *h, const uint32_t *priority, uint32_t n_priority)
     }
     prio[priority[i]] = 1;
   }
-  std::vector<uint32_t> sd[2], so[2], si[2];
-  so[0].push_back(0);
-  so[1].push_back(0);
-  auto add = [&](uint32_t dof, const uint32_t *slots, uint32_t k) {
-    const int g = prio[dof & 0x7fffffffu] ? 0 : 1;
+  const size_t ng = 1 + h->seg_end.size();
+  std::vector<std::vector<uint32_t>> sd(ng), so(ng, std::vector<uint32_t>(1, 0u)), si(ng);
+  auto add = [&](uint32_t dof, const uint32_t *slots, uint32_t k, size_t seg) {
+    const size_t g = prio[dof & 0x7fffffffu] ? 0 : 1 + seg;
     sd[g].push_back(dof);
     si[g].insert(si[g].end(), slots, slots + k);
     so[g].push_back((uint32_t)si[g].size());
   };
-  for (size_t i = 0; i < P.sdofs.size(); ++i) add(P.sdofs[i], P.s_idx.data() + P.s_off[i], P.s_off[i + 1] - P.s_off[i]);
+  for (size_t i = 0; i < P.sdofs.size(); ++i) {
+    // the slots of a dof are listed in ascending batch order: the last one belongs to its last toucher
+    size_t seg = 0;
+    if (P.s_off[i + 1] > P.s_off[i]) {
+      const uint32_t slot = P.s_idx[P.s_off[i + 1] - 1];
+      const uint32_t batch = (uint32_t)(std::upper_bound(P.halo_off.begin(), P.halo_off.end(), slot) - P.halo_off.begin()) - 1;
+      seg = (size_t)(std::upper_bound(h->seg_end.begin(), h->seg_end.end(), batch) - h->seg_end.begin());
+      if (seg >= h->seg_end.size()) seg = h->seg_end.size() - 1;
+    }
+    add(P.sdofs[i], P.s_idx.data() + P.s_off[i], P.s_off[i + 1] - P.s_off[i], seg);
+  }
   const uint32_t zero_slot = P.halo_off.empty() ? 0u : P.halo_off.back();
-  for (uint32_t orph : P.orphans) add(orph, &zero_slot, 1);
-  for (int g = 0; g < 2; ++g) {
+  for (uint32_t orph : P.orphans) add(orph, &zero_slot, 1, 0);  // depend on no batch
+  for (size_t g = 0; g < h->d_p2arr.size(); ++g) {
     hipFree(h->d_p2arr[g]);
     hipFree(h->d_p2tiles[g]);
-    h->d_p2arr[g] = h->d_p2tiles[g] = nullptr;
+  }
+  h->d_p2arr.assign(ng, nullptr);
+  h->d_p2tiles.assign(ng, nullptr);
+  h->n_p2tiles.assign(ng, 0u);
+  for (size_t g = 0; g < ng; ++g) {
     std::vector<uint32_t> arr, tiles;
     build_pass2_classes(sd[g], so[g], si[g], arr, tiles);
     h->n_p2tiles[g] = (uint32_t)(tiles.size() / 4);
@@ -148,7 +171,7 @@ int upload_pass2(mfgpu_handle *h, const uint32_t *priority, uint32_t n_priority)
 }
 
 template <typename T>
-int create_typed(mfgpu_handle *h, const mfgpu_desc &d) {
+int create_arrays(mfgpu_handle *h, const mfgpu_desc &d) {
   const Plan &P = h->plan;
   const size_t ncell = P.n_cells, nd = (size_t)P.nd;
   size_t &acct = h->device_bytes;
@@ -237,7 +260,6 @@ int create_typed(mfgpu_handle *h, const mfgpu_desc &d) {
   if (h->twopass) {
     if ((rc = dev_upload(&h->d_batch_nint, P.batch_nint.data(), P.batch_nint.size() * 4, acct))) return rc;
     if ((rc = dev_upload(&h->d_halo_off, P.halo_off.data(), P.halo_off.size() * 4, acct))) return rc;
-    if ((rc = upload_pass2(h, nullptr, 0))) return rc;
     if (h->pk && (uint64_t)P.halo_off.back() >= (1ull << 29)) {
       set_error("halo buffer too large for 32-bit byte offsets");
       return MFGPU_EUNSUPPORTED;
@@ -373,13 +395,96 @@ int create_typed(mfgpu_handle *h, const mfgpu_desc &d) {
   return 0;
 }
 
-// one vmult in three phases: the cell loop; pass 2 of the priority dofs; pass 2 of the rest.  mfgpu_vmult runs them back
+// Segments of the cell loop (see mfgpu_handle::seg_end).  request = mfgpu_desc.cell_loop_segments: 0 the library's
+// choice, 1 one segment (pass 2 strictly after the cell loop), k > 1 k segments of equal batch counts.  The choice:
+// where two kernel families share the mesh (plane batches | pencil batches of the cells with a hanging-node mask) the
+// family boundary -- the launch boundary exists anyway (C3: 0.381 instead of 0.392 ms per vmult); ONE segment
+// otherwise.  Measured on C2 (profiles/r02_notes.md section 6): with the last 4 of 13 grid iterations as a second
+// segment the two kernels do run side by side, but the cell loop slows down by what pass 2 takes (58.6 instead of
+// 37 us for the segment; both are short of issue slots and memory latency, not of different resources), and the event
+// record / cross-stream waits add three pipeline drains of 5-12 us per vmult: 0.171 instead of 0.156 ms.
+void choose_segments(mfgpu_handle *h, uint32_t request) {
+  const Plan &P = h->plan;
+  const uint32_t nb = (uint32_t)(P.batch_cell_off.size() - 1);
+  h->seg_end.assign(1, nb);
+  if (!h->twopass || nb < 2 || request == 1) return;
+  const uint32_t npl = h->pk ? P.n_plane_batches : 0u;
+  std::vector<uint32_t> cuts;
+  if (npl > 0 && npl < nb) cuts.push_back(npl);
+  if (request > 1) {
+    for (uint32_t i = 1; i < request; ++i) cuts.push_back((uint32_t)((uint64_t)nb * i / request));
+  }
+  std::sort(cuts.begin(), cuts.end());
+  h->seg_end.clear();
+  for (uint32_t c : cuts)
+    if (c > 0 && c < nb && (h->seg_end.empty() || h->seg_end.back() != c)) h->seg_end.push_back(c);
+  h->seg_end.push_back(nb);
+}
+
+template <typename T>
+int create_typed(mfgpu_handle *h, const mfgpu_desc &d) {
+  int rc = create_arrays<T>(h, d);
+  if (rc) return rc;
+  choose_segments(h, d.cell_loop_segments);
+  if (!h->twopass) return 0;
+  if (h->seg_end.size() > 1) {
+    // lowest priority: when a segment ends, the next segment's workgroups should be placed before the pass-2 waves,
+    // which fill the remaining wave slots
+    int prio_least = 0, prio_greatest = 0;
+    HIP_TRY(hipDeviceGetStreamPriorityRange(&prio_least, &prio_greatest));
+    HIP_TRY(hipStreamCreateWithPriority(&h->side, hipStreamNonBlocking, prio_least));
+    HIP_TRY(hipEventCreateWithFlags(&h->ev_side, hipEventDisableTiming));
+    h->ev_seg.assign(h->seg_end.size() - 1, nullptr);
+    for (hipEvent_t &e : h->ev_seg) HIP_TRY(hipEventCreateWithFlags(&e, hipEventDisableTiming));
+  }
+  return upload_pass2(h, nullptr, 0);
+}
+
+// one vmult in three phases: the cell loop (with pass 2 of the earlier segments' dofs on the side stream); pass 2 of
+// the priority dofs; pass 2 of the last segment's dofs and the join with the side stream.  mfgpu_vmult runs them back
 // to back; mfgpu_vmult_dist_begin starts the exchange of the slab's interface planes between the last two.
 template <typename T>
-int vmult_pass2(mfgpu_handle *h, int group, void *dst, const void *src, hipStream_t st, int add) {
-  if (h->twopass)
-    HIP_TRY(reduce_classes_launch<T>((T *)dst, (const T *)src, (const T *)h->d_halo, h->d_p2arr[group], h->d_p2tiles[group],
-                                     h->n_p2tiles[group], add, st));
+int launch_pass2_group(mfgpu_handle *h, size_t group, void *dst, const void *src, hipStream_t st, int add) {
+  HIP_TRY(reduce_classes_launch<T>((T *)dst, (const T *)src, (const T *)h->d_halo, h->d_p2arr[group], h->d_p2tiles[group],
+                                   h->n_p2tiles[group], add, st));
+  return 0;
+}
+
+template <typename T>
+int vmult_pass2(mfgpu_handle *h, int phase, void *dst, const void *src, hipStream_t st, int add) {
+  if (!h->twopass) return 0;
+  if (phase == 0) return launch_pass2_group<T>(h, 0, dst, src, st, add);
+  int rc = launch_pass2_group<T>(h, h->seg_end.size(), dst, src, st, add);
+  if (!rc && h->side_pending) {
+    HIP_TRY(hipStreamWaitEvent(st, h->ev_side, 0));
+    h->side_pending = false;
+  }
+  return rc;
+}
+
+// batches [b0, b1) of one scatter pass, each with the kernel family that owns it
+template <typename T>
+int launch_cells(mfgpu_handle *h, ApplyArgs<T> a, uint32_t b0, uint32_t b1, hipStream_t st) {
+  const Plan &P = h->plan;
+  const uint32_t npl = h->pk ? P.n_plane_batches : 0u;
+  if (b0 < npl) {  // the batches of cells without a hanging-node mask (all batches on conforming meshes)
+    a.batch0 = b0;
+    a.batch_end = b1 < npl ? b1 : npl;
+    const uint32_t nbat = a.batch_end - a.batch0;
+    HIP_TRY(p_launch<T>(P.n, a, h->S.data(), h->Dt.data(), nbat < h->max_grid_p ? nbat : h->max_grid_p, st, false,
+                        nullptr, nullptr));
+    b0 = a.batch_end;
+  }
+  if (b0 >= b1) return 0;
+  a.batch0 = b0;
+  a.batch_end = b1;
+  const uint32_t nrest = b1 - b0, grid = nrest < h->max_grid ? nrest : h->max_grid;
+  if (h->gk)
+    HIP_TRY(g_launch<T>(P.n, a, h->S.data(), h->Dt.data(), h->hn, grid, st, false, nullptr, nullptr));
+  else if (h->xk)
+    HIP_TRY(x_launch<T>(P.n, a, h->S.data(), h->Dt.data(), h->hn, grid, st, false, nullptr, nullptr));
+  else
+    HIP_TRY(apply_launch<T>(P.dim, P.n, a, h->S.data(), h->Dt.data(), h->hn, h->twopass, grid, st));
   return 0;
 }
 
@@ -412,47 +517,48 @@ int vmult_main(mfgpu_handle *h, void *dst, const void *src, hipStream_t st, int 
 #ifdef MFGPU_STAMPS
   if (const char *e = getenv("MFGPU_DBG")) a.dbg = atoi(e);
 #endif
-  // two-pass mode: ONE sweep over all batches (no inter-batch dependency), then the shared-dof sums;
-  // coloured mode: one launch per batch colour (first toucher stores, later colours add)
-  const size_t ncol = h->twopass ? 1 : P.color_batch_off.size() - 1;
-  for (size_t c = 0; c < ncol; ++c) {
-    a.batch0 = h->twopass ? 0u : P.color_batch_off[c];
-    const uint32_t nbat = (h->twopass ? (uint32_t)(P.batch_cell_off.size() - 1) : P.color_batch_off[c + 1]) - a.batch0;
-    if (nbat == 0) continue;
-    if (h->prof) {
-      if (h->ev_used + 2 > h->ev.size()) {
-        hipEvent_t e0, e1;
-        HIP_TRY(hipEventCreate(&e0));
-        HIP_TRY(hipEventCreate(&e1));
-        h->ev.push_back(e0);
-        h->ev.push_back(e1);
+  if (h->prof) {
+    if (h->ev_used + 2 > h->ev.size()) {
+      hipEvent_t e0, e1;
+      HIP_TRY(hipEventCreate(&e0));
+      HIP_TRY(hipEventCreate(&e1));
+      h->ev.push_back(e0);
+      h->ev.push_back(e1);
+    }
+    HIP_TRY(hipEventRecord(h->ev[h->ev_used], st));
+  }
+  if (h->twopass) {
+    // ONE sweep over all batches (no inter-batch dependency) in segments; after every segment but the last, the
+    // shared-dof sums that are complete by then start on the side stream
+    const size_t nseg = h->seg_end.size();
+    if (h->side_pending) {  // (a caller that ran phase 0 twice without the closing phase)
+      HIP_TRY(hipStreamWaitEvent(st, h->ev_side, 0));
+      h->side_pending = false;
+    }
+    for (size_t s = 0; s < nseg; ++s) {
+      int rc = launch_cells<T>(h, a, s ? h->seg_end[s - 1] : 0u, h->seg_end[s], st);
+      if (rc) return rc;
+      if (s + 1 < nseg) {
+        HIP_TRY(hipEventRecord(h->ev_seg[s], st));
+        HIP_TRY(hipStreamWaitEvent(h->side, h->ev_seg[s], 0));
+        if ((rc = launch_pass2_group<T>(h, 1 + s, dst, src, h->side, add))) return rc;
       }
-      HIP_TRY(hipEventRecord(h->ev[h->ev_used], st));
     }
-    a.batch_end = a.batch0 + nbat;
-    if (h->pk) {  // the batches of cells without a hanging-node mask (all batches on conforming meshes)
-      ApplyArgs<T> ap = a;
-      ap.batch_end = P.n_plane_batches;
-      HIP_TRY(p_launch<T>(P.n, ap, h->S.data(), h->Dt.data(),
-                          P.n_plane_batches < h->max_grid_p ? P.n_plane_batches : h->max_grid_p, st, false, nullptr,
-                          nullptr));
-      a.batch0 = P.n_plane_batches;
+    if (nseg > 1) {
+      HIP_TRY(hipEventRecord(h->ev_side, h->side));
+      h->side_pending = true;
     }
-    const uint32_t nrest = a.batch_end - a.batch0;
-    if (nrest == 0) {
-    } else if (h->gk)
-      HIP_TRY(g_launch<T>(P.n, a, h->S.data(), h->Dt.data(), h->hn, nrest < h->max_grid ? nrest : h->max_grid, st,
-                          false, nullptr, nullptr));
-    else if (h->xk)
-      HIP_TRY(x_launch<T>(P.n, a, h->S.data(), h->Dt.data(), h->hn, nrest < h->max_grid ? nrest : h->max_grid, st,
-                          false, nullptr, nullptr));
-    else
-      HIP_TRY(apply_launch<T>(P.dim, P.n, a, h->S.data(), h->Dt.data(), h->hn, h->twopass,
-                              nrest < h->max_grid ? nrest : h->max_grid, st));
-    if (h->prof) {
-      HIP_TRY(hipEventRecord(h->ev[h->ev_used + 1], st));
-      h->ev_used += 2;
+  } else {
+    // coloured mode: one launch per batch colour (first toucher stores, later colours add)
+    for (size_t c = 0; c + 1 < P.color_batch_off.size(); ++c) {
+      if (P.color_batch_off[c + 1] == P.color_batch_off[c]) continue;
+      int rc = launch_cells<T>(h, a, P.color_batch_off[c], P.color_batch_off[c + 1], st);
+      if (rc) return rc;
     }
+  }
+  if (h->prof) {
+    HIP_TRY(hipEventRecord(h->ev[h->ev_used + 1], st));
+    h->ev_used += 2;
   }
   if (!h->twopass)  // coloured mode has no pass 2: the dofs no cell touches get their own small kernel
     HIP_TRY(orphan_launch<T>((T *)dst, (const T *)src, h->d_orphans, (uint32_t)P.orphans.size(), add, st));
@@ -637,10 +743,17 @@ void mfgpu_destroy(mfgpu_handle *h) {
   hipFree(h->d_hnw);
   hipFree(h->d_batch_nint);
   hipFree(h->d_halo_off);
-  for (int g = 0; g < 2; ++g) {
+  for (size_t g = 0; g < h->d_p2arr.size(); ++g) {
     hipFree(h->d_p2arr[g]);
     hipFree(h->d_p2tiles[g]);
   }
+  if (h->side) {
+    hipStreamSynchronize(h->side);
+    hipStreamDestroy(h->side);
+  }
+  for (hipEvent_t e : h->ev_seg)
+    if (e) hipEventDestroy(e);
+  if (h->ev_side) hipEventDestroy(h->ev_side);
   hipFree(h->d_halo);
   hipFree(h->d_stamps);
   for (hipEvent_t e : h->ev) hipEventDestroy(e);

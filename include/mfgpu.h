@@ -93,6 +93,10 @@ typedef struct mfgpu_desc {
   uint32_t max_cells_per_batch;
   uint32_t max_dofs_per_batch;
   uint32_t kernel; /* MFGPU_KERNEL_*: which cell-loop kernel family to use; 0 = the library's choice */
+  uint32_t cell_loop_segments; /* two-pass mode: the cell loop runs as this many launches over consecutive batch
+                                  ranges; the shared-dof sums (pass 2) a finished range completes run on a side
+                                  stream of the handle, next to the following range's cells.  0 = the library's
+                                  choice, 1 = one launch, pass 2 strictly after it                              */
 } mfgpu_desc;
 
 /* mfgpu_desc.kernel (all variants compute the same operator; non-default ones exist for tests and measurements) */
