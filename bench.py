@@ -106,6 +106,8 @@ def main():
                          "(synthetic deformation F = h (I + EPS R), R random in [-1,1]); 1 GPU")
     ap.add_argument("--adaptive", type=int, default=0, metavar="NREF",
                     help="configs[2]: bmop -DADAPTIVE_GRID mesh with hanging nodes instead of the uniform cube (1 GPU)")
+    ap.add_argument("--ball", type=int, default=-1, metavar="NREF",
+                    help="bmop -DBALL_GRID: hyper_ball with NREF global refinements (unstructured, general-geometry path; 1 GPU)")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -127,7 +129,11 @@ def main():
     p = args.degree
     n_glob = int(round(args.cells * world ** (1.0 / 3.0)))
     zb, ze = slab_ranges(n_glob, world)[rank]
-    if args.adaptive:
+    if args.ball >= 0:
+        if world != 1:
+            raise SystemExit("--ball is a single-GPU configuration")
+        mesh = mf.Mesh.ball(3, p, args.ball, number_type=nt)
+    elif args.adaptive:
         if world != 1:
             raise SystemExit("--adaptive is a single-GPU configuration")
         mesh = mf.Mesh.adaptive(3, p, args.adaptive, number_type=nt)
@@ -161,7 +167,7 @@ def main():
     nd = (p + 1) ** 3
     n_dofs_glob = (p * n_glob + 1) ** 3
     n_cells_glob = n_glob ** 3
-    if args.adaptive:
+    if args.adaptive or args.ball >= 0:
         n_dofs_glob, n_cells_glob = mesh.n_dofs, mesh.n_cells
 
     dst = torch.full((N_loc,), 0.1, device=dev, dtype=tdt)  # bmop.cu:140
@@ -257,7 +263,8 @@ def main():
     op.profile_enable(False)
     launches = n_v * stats["n_launches"]
     b_alg_loc = algorithmic_bytes(N_loc, mesh.n_cells, nd, s)
-    if args.general_jacobian:  # per quadrature point: the 6 entries of the symmetric a JxW J J^T instead of one scalar
+    general = bool(args.general_jacobian) or args.ball >= 0
+    if general:  # per quadrature point: the 6 entries of the symmetric a JxW J J^T instead of one scalar
         b_alg_loc += mesh.n_cells * nd * 5 * s
     achieved = b_alg_loc * n_v / (k_ms * 1e-3) / 1e9  # GB/s, == (B_alg/launch) / (avg launch duration)
     # HBM traffic of the dominant kernel: NOT measured by this run (PMC counters need rocprofv3 passes of their own,
@@ -271,7 +278,7 @@ def main():
             if (tr.get("workload") == f"p{p}_3d_n{n_glob}_{'f32' if args.float else 'f64'}" and world == 1
                     and op.kernel_name() + "<" in tr.get("kernel", "") and tr.get("csrc_sha16") == csrc_sha16()
                     and not args.adaptive and not args.colored and not args.batch_cells and not args.batch_dofs
-                    and not args.general_jacobian and args.kernel == "auto"):
+                    and not general and args.kernel == "auto"):
                 traffic = tr["hbm_bytes_per_launch"]
                 traffic_source = {"file": "profiles/traffic_latest.json", "profile": tr.get("profile"),
                                   "csrc_sha16": tr.get("csrc_sha16")}
@@ -293,6 +300,9 @@ def main():
         "data": "synthetic",
         "config": {"workload": (f"bmop: DEGREE_FE={p}, DIMENSION=3, ADAPTIVE_GRID n_ref={args.adaptive}, hanging nodes, "
                                 f"{n_cells_glob} cells, {n_dofs_glob} DoFs") if args.adaptive else
+                               (f"bmop -DBALL_GRID: DEGREE_FE={p}, DIMENSION=3, hyper_ball, {args.ball} global refinements, "
+                                f"{n_cells_glob} cells, {n_dofs_glob} DoFs, MappingQ1 (full inverse Jacobian per quadrature "
+                                f"point); roofline bytes count the folded 6-entry metric (48 B / point)") if args.ball >= 0 else
                                (f"bmop without MATRIX_FREE_UNIFORM_MESH: DEGREE_FE={p}, DIMENSION=3, {n_glob}^3 cells, "
                                 f"{n_dofs_glob} DoFs, full inverse Jacobian per quadrature point (synthetic, eps="
                                 f"{args.general_jacobian}); roofline bytes count the folded 6-entry metric (48 B / point)")
@@ -309,7 +319,7 @@ def main():
                      "alg_bytes_per_launch": b_alg_loc / stats["n_launches"],
                      "kernel_ms_per_vmult": k_ms / max(n_v, 1)},
     }
-    if rank == 0 and world == 1 and not args.no_cpu and not args.adaptive and not args.general_jacobian:
+    if rank == 0 and world == 1 and not args.no_cpu and not args.adaptive and not general:
         cb, n_cpu, y_cpu = cpu_baseline(args)
         out["cpu_baseline"] = cb
         if n_cpu == n_glob and not args.float:

@@ -149,7 +149,7 @@ void Mesh::fill_desc(mfgpu_desc &d) const {
   d.dim = dim;
   d.degree = degree;
   d.number_type = number_type;
-  d.flags = MFGPU_UNIFORM_J0 | (constraint_mask.empty() ? 0u : MFGPU_HANGING_NODES);
+  d.flags = (general ? 0u : MFGPU_UNIFORM_J0) | (constraint_mask.empty() ? 0u : MFGPU_HANGING_NODES);
   d.n_dofs = n_dofs;
   d.n_cells = n_cells;
   d.loc2glob = loc2glob.data();

@@ -16,6 +16,7 @@ void lagrange_eval(const std::vector<double> &nodes, double x, std::vector<doubl
 
 struct Mesh {
   int dim = 0, degree = 0, number_type = MFGPU_F64;
+  bool general = false;  // inv_jac holds a full J^-1 per quadrature point (no MFGPU_UNIFORM_J0): ball meshes
   uint32_t n_dofs = 0, n_cells = 0;
   std::vector<double> nodes, xq, wq;  // 1D support points / Gauss points / weights on [0,1]
   std::vector<double> shape_values, shape_gradients, weights;
@@ -33,6 +34,7 @@ struct Mesh {
 
 int build_uniform(Mesh &M, const uint32_t *nper, double lo, double hi, uint32_t sb, uint32_t se);
 int build_adaptive(Mesh &M, int n_ref);
+int build_ball(Mesh &M, int n_ref);
 int build_from_tree_leaves(Mesh &M, int dim, std::vector<std::array<uint32_t, 4>> leaves);
 
 }  // namespace mfgpu

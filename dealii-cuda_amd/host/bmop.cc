@@ -1,6 +1,6 @@
 // bmop: operator benchmark, same command line, compile-time switches and output line as the
 // reference's bmop.cu (:45-64 N_ITERATIONS / DEGREE_FE / DIMENSION / BMOP_USE_FLOATS, :160-170
-// ADAPTIVE_GRID, :186-192 argv max_ref [min_ref], :152 "dim\tdegree\tn_dofs\tsec_per_vmult").
+// BALL_GRID / ADAPTIVE_GRID, :186-192 argv max_ref [min_ref], :152 "dim\tdegree\tn_dofs\tsec_per_vmult").
 // deal.II's mesh / dof classes are replaced by the stand-ins of mfgpu_shim.h; the operator runs
 // through the C-ABI on the MI355X.
 #include <chrono>
@@ -43,7 +43,12 @@ public:
 #else
     const bool pseudo_adaptive_grid = false;
 #endif
-    bmop_setup_mesh(triangulation, CUBE, pseudo_adaptive_grid, n_ref);
+#ifdef BALL_GRID
+    const domain_case_t domain = BALL;
+#else
+    const domain_case_t domain = CUBE;
+#endif
+    bmop_setup_mesh(triangulation, domain, pseudo_adaptive_grid, n_ref);
     setup_system();
     solve();
   }

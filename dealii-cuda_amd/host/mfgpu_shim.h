@@ -36,20 +36,25 @@ constexpr int number_type() {
 }
 
 // ---- deal.II stand-ins (setup side only) -----------------------------------------------------
-enum domain_case_t { CUBE, BALL };  // poisson_common.h: BALL is not implemented
+enum domain_case_t { CUBE, BALL };  // poisson_common.h:27-30
 
 template <int dim>
 class Triangulation {
 public:
   // bmop_setup_mesh (bmop_common.h:108-120) records the recipe; cells are created by DoFHandler
   bool adaptive = false;
+  domain_case_t domain = CUBE;
   int n_ref = 0;
   void refine_global(int times) { n_ref += times; }
 };
 
 template <int dim>
 void bmop_setup_mesh(Triangulation<dim> &tria, domain_case_t domain, bool pseudo_adaptive_grid, int n_ref) {
-  if (domain != CUBE) throw std::runtime_error("only the CUBE domain (hyper_cube(-1,1)) is implemented");
+  // BALL (hyper_ball + spherical boundary manifold, poisson_common.h:65-70): global refinement only -- the
+  // pseudo-adaptive recipe on the ball (bmop_common.h:58-70) needs hanging nodes on an unstructured mesh
+  if (domain == BALL && pseudo_adaptive_grid)
+    throw std::runtime_error("BALL_GRID with ADAPTIVE_GRID is not implemented (uniformly refined ball only)");
+  tria.domain = domain;
   tria.adaptive = pseudo_adaptive_grid;
   tria.n_ref = n_ref;
 }
@@ -91,7 +96,9 @@ public:
   void distribute_dofs(const FE_Q<dim> &fe, int number_type = MFGPU_F64) {
     clear();
     degree = fe.degree;
-    if (tria->adaptive) {
+    if (tria->domain == BALL) {
+      check(mfgpu_mesh_create_ball(dim, (int)fe.degree, tria->n_ref, number_type, &mesh), "mesh");
+    } else if (tria->adaptive) {
       check(mfgpu_mesh_create_adaptive(dim, (int)fe.degree, tria->n_ref, number_type, &mesh), "mesh");
     } else {
       uint32_t nper[3] = {1u << tria->n_ref, 1u << tria->n_ref, 1u << tria->n_ref};

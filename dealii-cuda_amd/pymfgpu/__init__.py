@@ -46,7 +46,7 @@ SYMBOLS = [
     "mfgpu_vec_dot", "mfgpu_vec_l2_norm", "mfgpu_vec_add_and_dot", "mfgpu_vec_all_zero", "mfgpu_profile_enable", "mfgpu_profile_read",
     "mfgpu_plan_create", "mfgpu_plan_destroy", "mfgpu_plan_array_u32", "mfgpu_plan_lmap", "mfgpu_plan_bflags",
     "mfgpu_vec_alloc", "mfgpu_vec_free", "mfgpu_vec_fill", "mfgpu_vec_from_host", "mfgpu_vec_to_host",
-    "mfgpu_device_synchronize", "mfgpu_device_memory_info", "mfgpu_mesh_create_uniform", "mfgpu_mesh_create_adaptive", "mfgpu_mesh_create_from_leaves",
+    "mfgpu_device_synchronize", "mfgpu_device_memory_info", "mfgpu_mesh_create_uniform", "mfgpu_mesh_create_adaptive", "mfgpu_mesh_create_ball", "mfgpu_mesh_create_from_leaves",
     "mfgpu_mesh_cell_levels", "mfgpu_mesh_destroy",
     "mfgpu_mesh_desc", "mfgpu_mesh_dof_coords", "mfgpu_mesh_interface_dofs",
     "mfgpu_dist_unique_id", "mfgpu_dist_create", "mfgpu_dist_connect_local", "mfgpu_dist_attach",
@@ -109,6 +109,7 @@ def lib():
         L.mfgpu_mesh_create_uniform.argtypes = [C.c_int, C.c_int, C.POINTER(C.c_uint32), C.c_double, C.c_double,
                                                 C.c_uint32, C.c_uint32, C.c_int, C.POINTER(C.c_void_p)]
         L.mfgpu_mesh_create_adaptive.argtypes = [C.c_int, C.c_int, C.c_int, C.c_int, C.POINTER(C.c_void_p)]
+        L.mfgpu_mesh_create_ball.argtypes = [C.c_int, C.c_int, C.c_int, C.c_int, C.POINTER(C.c_void_p)]
         L.mfgpu_mesh_create_from_leaves.argtypes = [C.c_int, C.c_int, C.c_void_p, C.c_uint32, C.c_int, C.POINTER(C.c_void_p)]
         L.mfgpu_mesh_cell_levels.argtypes = [C.c_void_p, C.POINTER(C.c_void_p)]
         L.mfgpu_mesh_cell_levels.restype = C.c_int64
@@ -164,6 +165,12 @@ class Mesh:
         return cls(h)
 
     @classmethod
+    def ball(cls, dim, degree, n_ref, number_type=F64):
+        h = C.c_void_p()
+        _check(lib().mfgpu_mesh_create_ball(dim, degree, n_ref, number_type, C.byref(h)))
+        return cls(h)
+
+    @classmethod
     def from_leaves(cls, dim, degree, leaves, number_type=F64):
         lv = np.ascontiguousarray(leaves, dtype=np.uint32).reshape(-1, 4)
         h = C.c_void_p()
@@ -200,7 +207,8 @@ class Mesh:
         out = dict(
             loc2glob=_view(d.loc2glob, nc * nd, np.uint32).reshape(nc, nd),
             JxW=_view(d.JxW, nc * nd, dt).reshape(nc, nd),
-            inv_jac=_view(d.inv_jac, nc, dt),
+            inv_jac=(_view(d.inv_jac, nc, dt) if d.flags & UNIFORM_J0
+                     else _view(d.inv_jac, nc * nd * d.dim * d.dim, dt).reshape(nc, nd, d.dim, d.dim)),
             quadrature_points=_view(d.quadrature_points, nc * nd * d.dim, dt).reshape(nc, nd, d.dim),
             shape_values=_view(d.shape_values, n * n, dt),
             shape_gradients=_view(d.shape_gradients, n * n, dt),

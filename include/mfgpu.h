@@ -238,6 +238,10 @@ int mfgpu_mesh_create_uniform(int dim, int degree, const uint32_t *n_per_dir, do
 /* bmop_common.h:49-105 pseudo_adaptive_refinement on the cube (ADAPTIVE_GRID), n_ref as in
  * bmop's argv; octree with 2:1 balance and hanging-node constraints.                          */
 int mfgpu_mesh_create_adaptive(int dim, int degree, int n_ref, int number_type, mfgpu_mesh **out);
+/* BALL domain of bmop / poisson (-DBALL_GRID; poisson_common.h:65-70, bmop_common.h:108-120): hyper_ball (unit
+ * ball, 5 / 7 coarse cells), spherical manifold on the boundary, n_ref global refinements, MappingQ1.  Unstructured;
+ * the description has a full J^-1 per quadrature point (no MFGPU_UNIFORM_J0).                                     */
+int mfgpu_mesh_create_ball(int dim, int degree, int n_ref, int number_type, mfgpu_mesh **out);
 /* same setup from an explicit one-irregular set of octree leaves (level, cx, cy, cz) x n_leaves on
  * hyper_cube(-1,1): lets tests build the awkward small cases of test_hanging_nodes_gpu.cu:297-331 */
 int mfgpu_mesh_create_from_leaves(int dim, int degree, const uint32_t *leaves, uint32_t n_leaves,

@@ -402,6 +402,9 @@ def test_bmop_driver_binaries():
     assert out.returncode == 0 and out.stdout.split("\t")[:3] == ["3", "4", str(65 ** 3)]
     out = subprocess.run([os.path.join(b, "bmop-3d-p4-adaptive"), "4", "4"], capture_output=True, text=True, timeout=120)
     assert out.returncode == 0 and out.stdout.split("\t")[:2] == ["3", "4"]
+    # -DBALL_GRID: hyper_ball, 3 global refinements = 7 * 8^3 cells, 232609 dofs at p = 4
+    out = subprocess.run([os.path.join(b, "bmop-3d-p4-ball"), "3", "3"], capture_output=True, text=True, timeout=120)
+    assert out.returncode == 0 and out.stdout.split("\t")[:3] == ["3", "4", "232609"]
 
 
 @pytest.mark.parametrize("p,n,world", [(4, 7, 2), (2, 9, 3), (4, 12, 4)])
