@@ -41,6 +41,7 @@ struct mfgpu_handle {
   void *d_hnw = nullptr;
   uint32_t *d_constrained = nullptr;  // constrained dof list (set_constrained_values)
   uint32_t n_constrained = 0;
+  void *d_tabsd = nullptr;  // apply_batches_g2: [S | Dt] full 1D tables in the operator's number type
   void *d_tab2 = nullptr;  // [2][n*n] squared 1D tables of the diagonal kernel, built on first use
   // two-pass mode
   bool twopass = true;
@@ -306,11 +307,13 @@ int create_arrays(mfgpu_handle *h, const mfgpu_desc &d) {
   const size_t jac_per_cell = h->gk ? nd * (size_t)(P.dim * P.dim) : 1;  // full J^-1 per point, or one scalar per cell
   if ((rc = dev_upload(&t_j0, d.inv_jac, ncell * jac_per_cell * sizeof(T), tmp))) { cleanup(); return rc; }
   if ((rc = dev_upload(&t_order, P.cell_order.data(), ncell * 4, tmp))) { cleanup(); return rc; }
-  const size_t coef_per_point = h->gk ? 6 : 1;  // symmetric M = a JxW J J^T, or the scalar a J0^2 JxW
+  // symmetric M = a JxW J^-1 J^-T (6 entries in 3D, 3 in 2D), or the scalar a J0^2 JxW
+  const size_t coef_per_point = h->gk ? (P.dim == 3 ? 6 : 3) : 1;
   hipError_t e = hipMalloc(&h->d_coef, ncell * nd * coef_per_point * sizeof(T));
   if (e == hipSuccess) {
     acct += ncell * nd * coef_per_point * sizeof(T);
-    e = h->gk ? fold_general_launch<T>((T *)h->d_coef, t_coef, t_jxw, t_j0, t_order, (uint32_t)ncell, (uint32_t)nd, nullptr)
+    e = h->gk ? (P.dim == 3 ? fold_general_launch<T>((T *)h->d_coef, t_coef, t_jxw, t_j0, t_order, (uint32_t)ncell, (uint32_t)nd, nullptr)
+                            : fold_general2_launch<T>((T *)h->d_coef, t_coef, t_jxw, t_j0, t_order, (uint32_t)ncell, (uint32_t)nd, nullptr))
               : fold_launch<T>((T *)h->d_coef, t_coef, t_jxw, t_j0, t_order, (uint32_t)ncell, (uint32_t)nd, nullptr);
   }
   if (e == hipSuccess) e = hipDeviceSynchronize();
@@ -370,7 +373,15 @@ int create_arrays(mfgpu_handle *h, const mfgpu_desc &d) {
   dummy.nb_max = P.max_batch_dofs;
   int per_cu = 0, dev = 0;
   hipDeviceProp_t prop;
-  if (h->gk) {
+  if (h->gk && P.dim == 2) {
+    std::vector<T> sd(2 * (size_t)P.n * P.n);
+    for (int i = 0; i < P.n * P.n; ++i) {
+      sd[i] = (T)h->S[i];
+      sd[P.n * P.n + i] = (T)h->Dt[i];
+    }
+    if ((rc = dev_upload((T **)&h->d_tabsd, sd.data(), sd.size() * sizeof(T), acct))) return rc;
+    HIP_TRY(g2_launch<T>(P.n, dummy, h->hn, 0, nullptr, true, &h->lds, nullptr));
+  } else if (h->gk) {
     HIP_TRY(g_launch<T>(P.n, dummy, nullptr, nullptr, h->hn, 0, nullptr, true, &h->lds, nullptr));
   } else if (h->xk) {
     HIP_TRY(x_launch<T>(P.n, dummy, nullptr, nullptr, h->hn, 0, nullptr, true, &h->lds, nullptr));
@@ -381,7 +392,9 @@ int create_arrays(mfgpu_handle *h, const mfgpu_desc &d) {
     set_error("batch needs more than 160 KiB of LDS; lower max_dofs_per_batch");
     return MFGPU_EINVAL;
   }
-  if (h->gk) {
+  if (h->gk && P.dim == 2) {
+    HIP_TRY(g2_launch<T>(P.n, dummy, h->hn, 0, nullptr, true, &h->lds, &per_cu));
+  } else if (h->gk) {
     HIP_TRY(g_launch<T>(P.n, dummy, nullptr, nullptr, h->hn, 0, nullptr, true, &h->lds, &per_cu));
   } else if (h->xk) {
     HIP_TRY(x_launch<T>(P.n, dummy, nullptr, nullptr, h->hn, 0, nullptr, true, &h->lds, &per_cu));
@@ -479,7 +492,9 @@ int launch_cells(mfgpu_handle *h, ApplyArgs<T> a, uint32_t b0, uint32_t b1, hipS
   a.batch0 = b0;
   a.batch_end = b1;
   const uint32_t nrest = b1 - b0, grid = nrest < h->max_grid ? nrest : h->max_grid;
-  if (h->gk)
+  if (h->gk && P.dim == 2)
+    HIP_TRY(g2_launch<T>(P.n, a, h->hn, grid, st, false, nullptr, nullptr));
+  else if (h->gk)
     HIP_TRY(g_launch<T>(P.n, a, h->S.data(), h->Dt.data(), h->hn, grid, st, false, nullptr, nullptr));
   else if (h->xk)
     HIP_TRY(x_launch<T>(P.n, a, h->S.data(), h->Dt.data(), h->hn, grid, st, false, nullptr, nullptr));
@@ -505,6 +520,8 @@ int vmult_main(mfgpu_handle *h, void *dst, const void *src, hipStream_t st, int 
   a.coef = (const T *)h->d_coef;
   a.cmask = h->d_cmask;
   a.hn_weights = (const T *)h->d_hnw;
+  a.tabS = (const T *)h->d_tabsd;
+  a.tabDt = h->d_tabsd ? (const T *)h->d_tabsd + (size_t)P.n * P.n : nullptr;
   a.batch_nint = h->d_batch_nint;
   a.halo_off = h->d_halo_off;
   a.halo = (T *)h->d_halo;
@@ -594,7 +611,11 @@ int inverse_diagonal_typed(mfgpu_handle *h, void *diag, hipStream_t st) {
   // inv_diag.reinit(m()): zero  (laplace_operator_gpu.h:407)
   HIP_TRY(fill_launch<T>((T *)diag, P.n_dofs, T(0), st));
   // data.cell_loop(inv_diag, diag_loc_op)  (:409-410)
-  if (h->gk)
+  if (h->gk && P.dim == 2)
+    HIP_TRY(diag_general2_launch<T>(P.n, (T *)diag, (uint32_t)(P.batch_cell_off.size() - 1), h->d_batch_cell_off,
+                                    h->d_batch_dof_off, h->d_bdofs, h->d_lmap, (const T *)h->d_coef, h->d_cmask,
+                                    (const T *)h->d_hnw, (const T *)h->d_tab2, st));
+  else if (h->gk)
     HIP_TRY(diag_general_launch<T>(P.n, (T *)diag, (uint32_t)(P.batch_cell_off.size() - 1), h->d_batch_cell_off,
                                    h->d_batch_dof_off, h->d_bdofs, h->d_lmap, (const T *)h->d_coef, h->d_cmask,
                                    (const T *)h->d_hnw, (const T *)h->d_tab2, st));
@@ -669,9 +690,8 @@ int mfgpu_create(const mfgpu_desc *desc, mfgpu_handle **out) {
     return MFGPU_EINVAL;
   }
   const bool general = !(d.flags & MFGPU_UNIFORM_J0);
-  if (general && (d.dim != 3 || (d.flags & MFGPU_COLORED_SCATTER))) {
-    set_error("the general-Jacobian path (no MFGPU_UNIFORM_J0) is implemented for 3D meshes in two-pass "
-              "scatter mode only");
+  if (general && (d.flags & MFGPU_COLORED_SCATTER)) {
+    set_error("the general-Jacobian path (no MFGPU_UNIFORM_J0) is implemented in two-pass scatter mode only");
     return MFGPU_EUNSUPPORTED;
   }
   if (!d.JxW || !d.inv_jac || !d.shape_values || !d.shape_gradients ||
@@ -737,6 +757,7 @@ void mfgpu_destroy(mfgpu_handle *h) {
   hipFree(h->d_coefp);
   hipFree(h->d_constrained);
   hipFree(h->d_tab2);
+  hipFree(h->d_tabsd);
   hipFree(h->d_coef);
   hipFree(h->d_cmask);
   hipFree(h->d_orphans);
@@ -812,7 +833,7 @@ int mfgpu_plan_stats(const mfgpu_handle *h, uint64_t s[8]) {
 const char *mfgpu_kernel_name(const mfgpu_handle *h) {
   if (!h) return "";
   return h->pk ? (h->xk ? "apply_planes3+apply_batches_x" : "apply_planes3")
-               : h->gk ? "apply_batches_g" : h->xk ? "apply_batches_x" : "apply_batches";
+               : h->gk ? (h->dim == 2 ? "apply_batches_g2" : "apply_batches_g") : h->xk ? "apply_batches_x" : "apply_batches";
 }
 
 int mfgpu_profile_enable(mfgpu_handle *h, int on) {

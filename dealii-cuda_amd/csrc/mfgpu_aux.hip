@@ -182,6 +182,64 @@ hipError_t diag_general_launch(int n, T *diag, uint32_t n_batches, const uint32_
   return hipGetLastError();
 }
 
+// the same in 2D: metric[cell][e][q], e = xx, xy, yy
+template <int n, typename T>
+__global__ void __launch_bounds__(256)
+diag_general2_kernel(T *diag, const uint32_t *batch_cell_off, const uint32_t *batch_dof_off, const uint32_t *bdofs,
+                     const uint16_t *lmap, const T *metric, const uint32_t *cmask, const T *hn_weights, const T *tab) {
+  constexpr int nd = n * n;
+  __shared__ T S[nd], G[nd], Wl[nd], loc[nd], m[3 * nd];
+  const int tid = threadIdx.x;
+  for (int t = tid; t < nd; t += 256) {
+    S[t] = tab[t];
+    G[t] = tab[nd + t];
+    Wl[t] = hn_weights ? hn_weights[t] : T(0);
+  }
+  const uint32_t b = blockIdx.x;
+  const uint32_t c0 = batch_cell_off[b], c1 = batch_cell_off[b + 1], d0 = batch_dof_off[b];
+  for (uint32_t c = c0; c < c1; ++c) {
+    __syncthreads();
+    for (int i = tid; i < 3 * nd; i += 256) m[i] = metric[(size_t)c * (3 * nd) + i];
+    __syncthreads();
+    for (int i = tid; i < nd; i += 256) {
+      const int ix = i % n, iy = i / n;
+      T sum = T(0);
+      for (int qy = 0; qy < n; ++qy)
+        for (int qx = 0; qx < n; ++qx) {
+          const int q = qx + n * qy;
+          const T gx = G[ix * n + qx] * S[iy * n + qy], gy = S[ix * n + qx] * G[iy * n + qy];
+          sum += m[q] * gx * gx + m[2 * nd + q] * gy * gy + T(2) * m[nd + q] * gx * gy;
+        }
+      loc[i] = sum;
+    }
+    __syncthreads();
+    hn_transpose_local<2, n, T>(loc, Wl, cmask ? cmask[c] : 0u, tid);
+    for (int i = tid; i < nd; i += 256) {
+      const uint32_t g = bdofs[d0 + lmap[(size_t)c * nd + i]];
+      if (!(g >> 31)) atomicAdd(diag + g, loc[i]);
+    }
+  }
+}
+
+template <typename T>
+hipError_t diag_general2_launch(int n, T *diag, uint32_t n_batches, const uint32_t *batch_cell_off,
+                                const uint32_t *batch_dof_off, const uint32_t *bdofs, const uint16_t *lmap,
+                                const T *metric, const uint32_t *cmask, const T *hn_weights, const T *tab,
+                                hipStream_t st) {
+  if (n_batches == 0) return hipSuccess;
+#define DG2_CASE(N)                                                                                           \
+  case N:                                                                                                     \
+    hipLaunchKernelGGL((diag_general2_kernel<N, T>), dim3(n_batches), dim3(256), 0, st, diag, batch_cell_off, \
+                       batch_dof_off, bdofs, lmap, metric, cmask, hn_weights, tab);                           \
+    break;
+  switch (n) {
+    DG2_CASE(2) DG2_CASE(3) DG2_CASE(4) DG2_CASE(5) DG2_CASE(6) DG2_CASE(7)
+    default: return hipErrorInvalidValue;
+  }
+#undef DG2_CASE
+  return hipGetLastError();
+}
+
 template <typename T>
 __global__ void set_values_kernel(T *v, const uint32_t *idx, uint32_t n, T value) {
   const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
@@ -339,6 +397,9 @@ hipError_t vec_reduce_launch(int op, T *v, const T *x, const T *w, T a, size_t n
   template hipError_t diag_general_launch<T>(int, T *, uint32_t, const uint32_t *, const uint32_t *, const uint32_t *, \
                                              const uint16_t *, const T *, const uint32_t *, const T *, const T *, \
                                              hipStream_t);                                                   \
+  template hipError_t diag_general2_launch<T>(int, T *, uint32_t, const uint32_t *, const uint32_t *, const uint32_t *, \
+                                              const uint16_t *, const T *, const uint32_t *, const T *, const T *, \
+                                              hipStream_t);                                                  \
   template hipError_t set_values_launch<T>(T *, const uint32_t *, uint32_t, T, hipStream_t);                  \
   template hipError_t vec_map_launch<T>(int, T *, const T *, T, T, size_t, hipStream_t);                      \
   template hipError_t vec_reduce_launch<T>(int, T *, const T *, const T *, T, size_t, hipStream_t, double *);

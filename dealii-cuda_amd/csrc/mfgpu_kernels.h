@@ -24,6 +24,7 @@ struct ApplyArgs {
   const T *coef;          // folded a*J0^2*JxW (apply_batches_g: the 6 entries of a*JxW*J*J^T), plan cell order
   const uint32_t *cmask;  // plan cell order, or nullptr
   const T *hn_weights;    // [n*n] W[i*n+j] (device), or nullptr
+  const T *tabS, *tabDt;  // apply_batches_g2: full 1D tables S[i*n+q], Dt[q*n+t] on the device (nullptr otherwise)
   const uint32_t *batch_nint;  // two-pass mode: interior dofs per batch
   const uint32_t *halo_off;    // two-pass mode: first halo slot per batch
   T *halo;                     // two-pass mode: partial sums of shared dofs
@@ -77,6 +78,13 @@ hipError_t g_launch(int n, const ApplyArgs<T> &a, const double *S, const double 
 template <typename T>
 hipError_t fold_general_launch(T *M, const T *coef, const T *jxw, const T *jinv, const uint32_t *order,
                                uint32_t n_cells, uint32_t nd, hipStream_t st);
+// general-Jacobian cell loop in 2D (mfgpu_kernels_g2.hip; two-pass mode) and its setup fold (3 metric entries per point)
+template <typename T>
+hipError_t g2_launch(int n, const ApplyArgs<T> &a, bool hn, uint32_t grid, hipStream_t st, bool configure_only,
+                     size_t *lds_out, int *occupancy);
+template <typename T>
+hipError_t fold_general2_launch(T *M, const T *coef, const T *jxw, const T *jinv, const uint32_t *order,
+                                uint32_t n_cells, uint32_t nd, hipStream_t st);
 template <typename T>
 hipError_t orphan_launch(T *dst, const T *src, const uint32_t *orph, uint32_t n, int add, hipStream_t st);
 template <typename T>
@@ -97,6 +105,11 @@ hipError_t diag_general_launch(int n, T *diag, uint32_t n_batches, const uint32_
                                const uint32_t *batch_dof_off, const uint32_t *bdofs, const uint16_t *lmap,
                                const T *metric, const uint32_t *cmask, const T *hn_weights, const T *tab,
                                hipStream_t st);
+template <typename T>
+hipError_t diag_general2_launch(int n, T *diag, uint32_t n_batches, const uint32_t *batch_cell_off,
+                                const uint32_t *batch_dof_off, const uint32_t *bdofs, const uint16_t *lmap,
+                                const T *metric, const uint32_t *cmask, const T *hn_weights, const T *tab,
+                                hipStream_t st);
 template <typename T>
 hipError_t set_values_launch(T *v, const uint32_t *idx, uint32_t n, T value, hipStream_t st);
 // op: 0 sadd (v = s v + a w), 1 equ (v = a w), 2 scale (v *= w), 3 divide (v /= w), 4 invert, 5 mul (v *= a)

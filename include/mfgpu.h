@@ -44,9 +44,9 @@ extern "C" {
                                          (MATRIX_FREE_UNIFORM_MESH, matrix_free_gpu.cu:332-334,
                                          fee_gpu.cuh:225-241).  Without it: the reference's default
                                          geometry path, a full J^-1 per quadrature point (fee_gpu.cuh:
-                                         235-241,275-281) -- implemented for dim = 3 in
-                                         two-pass scatter mode (with or without hanging nodes); other
-                                         combinations return MFGPU_EUNSUPPORTED                     */
+                                         235-241,275-281) -- implemented in two-pass
+                                         scatter mode (2D and 3D, with or without hanging nodes); with
+                                         MFGPU_COLORED_SCATTER: MFGPU_EUNSUPPORTED                  */
 #define MFGPU_HANGING_NODES (1u << 1) /* constraint_mask is given (MATRIX_FREE_HANGING_NODES,
                                          fee_gpu.cuh:333-335,349-351)                           */
 

@@ -185,7 +185,7 @@ def test_errors_are_loud():
     with pytest.raises(mf.MfgpuError, match="alias"):
         op.vmult(v, v)
     d2 = mf.Desc.from_buffer_copy(mesh.desc)
-    d2.flags = 0  # the general-Jacobian path covers 3D only: a 2D description must be refused, not fall back
+    d2.flags = mf.COLORED_SCATTER  # general-Jacobian path (no UNIFORM_J0): two-pass scatter mode only, no fallback
     with pytest.raises(mf.MfgpuError, match="UNIFORM_J0"):
         mf.Operator(d2, mesh)
 
@@ -405,6 +405,9 @@ def test_bmop_driver_binaries():
     # -DBALL_GRID: hyper_ball, 3 global refinements = 7 * 8^3 cells, 232609 dofs at p = 4
     out = subprocess.run([os.path.join(b, "bmop-3d-p4-ball"), "3", "3"], capture_output=True, text=True, timeout=120)
     assert out.returncode == 0 and out.stdout.split("\t")[:3] == ["3", "4", "232609"]
+    # 2D ball: 5 * 4^5 cells; p = 2: 20609 dofs (vertices + lines + cells)
+    out = subprocess.run([os.path.join(b, "bmop-2d-p2-ball"), "5", "5"], capture_output=True, text=True, timeout=120)
+    assert out.returncode == 0 and out.stdout.split("\t")[:3] == ["2", "2", "20609"]
 
 
 @pytest.mark.parametrize("p,n,world", [(4, 7, 2), (2, 9, 3), (4, 12, 4)])
