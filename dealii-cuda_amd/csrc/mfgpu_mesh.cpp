@@ -178,6 +178,8 @@ int build_uniform(Mesh &M, const uint32_t *nper, double lo, double hi, uint32_t 
     return MFGPU_EINVAL;
   }
   ncl[dim - 1] = se - sb;
+  M.mg_kind = (sb == 0 && se == nc[dim - 1]) ? 0 : -1;
+  for (int d = 0; d < 3; ++d) M.nper[d] = nc[d];
   uint64_t ndofs64 = 1, ncells64 = 1;
   for (int d = 0; d < dim; ++d) {
     ng[d] = ncl[d] * p + 1;
@@ -264,6 +266,53 @@ int build_uniform(Mesh &M, const uint32_t *nper, double lo, double hi, uint32_t 
   return 0;
 }
 
+int mesh_transfer_patches(const Mesh &C, const Mesh &F, std::vector<uint32_t> &cd, std::vector<uint32_t> &fd) {
+  const int dim = C.dim, p = C.degree, n = p + 1, nf = 2 * p + 1;
+  if (F.dim != dim || F.degree != p || C.mg_kind < 0 || C.mg_kind != F.mg_kind) {
+    set_error("multigrid transfer: the two meshes are not a level pair of a supported kind");
+    return MFGPU_EUNSUPPORTED;
+  }
+  if (C.mg_kind == 0) {
+    for (int d = 0; d < dim; ++d)
+      if (F.nper[d] != 2 * C.nper[d]) {
+        set_error("multigrid transfer: the fine mesh is not the global refinement of the coarse one");
+        return MFGPU_EINVAL;
+      }
+  } else if ((uint64_t)F.n_cells != ((uint64_t)C.n_cells << dim)) {
+    set_error("multigrid transfer: the fine mesh is not the global refinement of the coarse one");
+    return MFGPU_EINVAL;
+  }
+  const int nd = ipow(n, dim), NF = ipow(nf, dim);
+  cd = C.loc2glob;
+  fd.assign((size_t)C.n_cells * NF, 0u);
+  for (uint32_t c = 0; c < C.n_cells; ++c) {
+    uint32_t cc[3] = {0, 0, 0};
+    if (C.mg_kind == 0) {
+      uint32_t r = c;
+      for (int d = 0; d < dim; ++d) {
+        cc[d] = r % C.nper[d];
+        r /= C.nper[d];
+      }
+    }
+    for (int t = 0; t < NF; ++t) {
+      int X[3] = {t % nf, (t / nf) % nf, dim == 3 ? t / (nf * nf) : 0};
+      int child = 0, local = 0, stride = 1;
+      uint64_t fcell = 0, fstride = 1;
+      for (int d = 0; d < dim; ++d) {
+        const int a = X[d] > p ? 1 : 0;
+        child |= a << d;
+        local += (X[d] - a * p) * stride;
+        stride *= n;
+        fcell += (uint64_t)(2 * cc[d] + a) * fstride;
+        fstride *= F.nper[d];
+      }
+      if (C.mg_kind != 0) fcell = ((uint64_t)c << dim) + child;
+      fd[(size_t)c * NF + t] = F.loc2glob[fcell * nd + local];
+    }
+  }
+  return 0;
+}
+
 }  // namespace mfgpu
 
 extern "C" {
@@ -296,6 +345,20 @@ int mfgpu_mesh_create_uniform(int dim, int degree, const uint32_t *n_per_dir, do
 }
 
 void mfgpu_mesh_destroy(mfgpu_mesh *m) { delete m; }
+
+int64_t mfgpu_mesh_transfer_patches(const mfgpu_mesh *coarse, const mfgpu_mesh *fine, uint32_t *coarse_cell_dofs,
+                                    uint32_t *fine_patch_dofs) {
+  if (!coarse || !fine || !coarse_cell_dofs || !fine_patch_dofs) {
+    mfgpu::set_error("mfgpu_mesh_transfer_patches: null argument");
+    return MFGPU_EINVAL;
+  }
+  std::vector<uint32_t> cd, fd;
+  int rc = mfgpu::mesh_transfer_patches(coarse->mesh, fine->mesh, cd, fd);
+  if (rc) return rc;
+  std::memcpy(coarse_cell_dofs, cd.data(), cd.size() * 4);
+  std::memcpy(fine_patch_dofs, fd.data(), fd.size() * 4);
+  return (int64_t)coarse->mesh.n_cells;
+}
 
 int mfgpu_mesh_desc(const mfgpu_mesh *m, mfgpu_desc *desc) {
   if (!m || !desc) {

@@ -272,6 +272,7 @@ int build_ball(Mesh &M, int n_ref) {
   const size_t nc = B.cells.size();
   M.n_cells = (uint32_t)nc;
   M.general = true;
+  M.mg_kind = 1;  // refinement-tree order, children lexicographic
   M.init_tables();
   M.loc2glob.assign(nc * nd, 0u);
   M.constraint_mask.clear();

@@ -51,6 +51,9 @@ SYMBOLS = [
     "mfgpu_mesh_desc", "mfgpu_mesh_dof_coords", "mfgpu_mesh_interface_dofs",
     "mfgpu_dist_unique_id", "mfgpu_dist_create", "mfgpu_dist_connect_local", "mfgpu_dist_attach",
     "mfgpu_vmult_dist_begin", "mfgpu_vmult_dist_end", "mfgpu_vmult_dist", "mfgpu_dist_destroy",
+    "mfgpu_transfer_create", "mfgpu_transfer_create_from_meshes", "mfgpu_transfer_prolongate",
+    "mfgpu_transfer_restrict_and_add", "mfgpu_transfer_memory_consumption", "mfgpu_transfer_destroy",
+    "mfgpu_mesh_transfer_patches",
 ]
 
 _lib = None
@@ -120,6 +123,17 @@ def lib():
         L.mfgpu_mesh_dof_coords.restype = C.c_int64
         L.mfgpu_mesh_interface_dofs.argtypes = [C.c_void_p, C.c_int, C.POINTER(C.c_void_p)]
         L.mfgpu_mesh_interface_dofs.restype = C.c_int64
+        L.mfgpu_transfer_create.argtypes = [C.c_int, C.c_int, C.c_int, C.c_uint32, C.c_void_p, C.c_void_p, C.c_uint32,
+                                            C.c_uint32, C.c_void_p, C.c_uint32, C.c_void_p, C.POINTER(C.c_void_p)]
+        L.mfgpu_transfer_create_from_meshes.argtypes = [C.c_void_p, C.c_void_p, C.POINTER(C.c_void_p)]
+        L.mfgpu_transfer_prolongate.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
+        L.mfgpu_transfer_restrict_and_add.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
+        L.mfgpu_transfer_memory_consumption.argtypes = [C.c_void_p]
+        L.mfgpu_transfer_memory_consumption.restype = C.c_size_t
+        L.mfgpu_mesh_transfer_patches.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
+        L.mfgpu_mesh_transfer_patches.restype = C.c_int64
+        L.mfgpu_transfer_destroy.argtypes = [C.c_void_p]
+        L.mfgpu_transfer_destroy.restype = None
         _lib = L
     return _lib
 
@@ -222,6 +236,16 @@ class Mesh:
         p = C.c_void_p()
         cnt = lib().mfgpu_mesh_dof_coords(self._h, C.byref(p))
         return _view(p.value, cnt, np.float64).reshape(-1, self.desc.dim)
+
+    def transfer_patches(self, fine: "Mesh"):
+        """(coarse_cell_dofs, fine_patch_dofs) of the level pair (self, fine): host arrays, no GPU"""
+        p, dim = self.desc.degree, self.desc.dim
+        cd = np.zeros((self.n_cells, (p + 1) ** dim), dtype=np.uint32)
+        fd = np.zeros((self.n_cells, (2 * p + 1) ** dim), dtype=np.uint32)
+        rc = lib().mfgpu_mesh_transfer_patches(self._h, fine._h, cd.ctypes.data, fd.ctypes.data)
+        if rc < 0:
+            _check(int(rc))
+        return cd, fd
 
     def interface_dofs(self, which):
         p = C.c_void_p()
@@ -460,6 +484,48 @@ class Operator:
         ms, nv = C.c_double(), C.c_uint64()
         _check(lib().mfgpu_profile_read(self._h, C.byref(ms), C.byref(nv)))
         return ms.value, int(nv.value)
+
+
+class Transfer:
+    """MGTransferMatrixFreeGpu between two globally refined levels (mfgpu_transfer_*)."""
+
+    def __init__(self, handle):
+        self._h = handle
+
+    @classmethod
+    def from_arrays(cls, dim, degree, coarse_cell_dofs, fine_patch_dofs, n_coarse_dofs, n_fine_dofs, coarse_dirichlet,
+                    number_type=F64, prolongation_1d=None):
+        cd = np.ascontiguousarray(coarse_cell_dofs, dtype=np.uint32)
+        fd = np.ascontiguousarray(fine_patch_dofs, dtype=np.uint32)
+        di = np.ascontiguousarray(coarse_dirichlet, dtype=np.uint32)
+        p1 = None if prolongation_1d is None else np.ascontiguousarray(prolongation_1d, dtype=np.float64)
+        n_cells = cd.size // ((degree + 1) ** dim)
+        assert fd.size == n_cells * (2 * degree + 1) ** dim
+        h = C.c_void_p()
+        _check(lib().mfgpu_transfer_create(dim, degree, number_type, n_cells, cd.ctypes.data, fd.ctypes.data, n_coarse_dofs,
+                                           n_fine_dofs, di.ctypes.data if di.size else None, di.size,
+                                           None if p1 is None else p1.ctypes.data, C.byref(h)))
+        return cls(h)
+
+    @classmethod
+    def from_meshes(cls, coarse: "Mesh", fine: "Mesh"):
+        h = C.c_void_p()
+        _check(lib().mfgpu_transfer_create_from_meshes(coarse._h, fine._h, C.byref(h)))
+        return cls(h)
+
+    def prolongate(self, dst_fine, src_coarse, stream=None):
+        _check(lib().mfgpu_transfer_prolongate(self._h, _ptr(dst_fine), _ptr(src_coarse), stream))
+
+    def restrict_and_add(self, dst_coarse, src_fine, stream=None):
+        _check(lib().mfgpu_transfer_restrict_and_add(self._h, _ptr(dst_coarse), _ptr(src_fine), stream))
+
+    def memory_consumption(self):
+        return int(lib().mfgpu_transfer_memory_consumption(self._h))
+
+    def __del__(self):
+        if getattr(self, "_h", None) and _lib is not None:
+            _lib.mfgpu_transfer_destroy(self._h)
+            self._h = None
 
 
 def _ptr(v):

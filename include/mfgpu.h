@@ -224,6 +224,27 @@ int mfgpu_vmult_dist_end(mfgpu_handle *h, mfgpu_dist *d, void *dst_dev, void *st
 int mfgpu_vmult_dist(mfgpu_handle *h, mfgpu_dist *d, void *dst_dev, const void *src_dev, void *stream);
 void mfgpu_dist_destroy(mfgpu_dist *d);
 
+/* ---- multigrid level transfer (MGTransferMatrixFreeGpu, mg_transfer_matrix_free_gpu.h:140-252,
+ * mg_transfer_matrix_free_gpu.cu:391-660) between two globally refined levels.  The boundary is the output of
+ * MGTransferMatrixFreeGpu::build (:150-330): per coarse cell its (p+1)^dim level dofs and the (2p+1)^dim level dofs of
+ * the patch of its children, both lexicographic (level_dof_indices), the coarse level's Dirichlet dofs
+ * (dirichlet_indices) and the 1D prolongation matrix (shape_values; NULL = FE_Q on Gauss-Lobatto nodes).  The level
+ * operators are ordinary mfgpu_handles of the level meshes (LaplaceOperatorGpu::reinit(dof_handler,
+ * mg_constrained_dofs, level), laplace_operator_gpu.h:154-186).                                                      */
+typedef struct mfgpu_transfer mfgpu_transfer;
+int mfgpu_transfer_create(int dim, int degree, int number_type, uint32_t n_coarse_cells,
+                          const uint32_t *coarse_cell_dofs /* [n_coarse_cells * (p+1)^dim]  */,
+                          const uint32_t *fine_patch_dofs  /* [n_coarse_cells * (2p+1)^dim] */, uint32_t n_coarse_dofs,
+                          uint32_t n_fine_dofs, const uint32_t *coarse_dirichlet, uint32_t n_coarse_dirichlet,
+                          const double *prolongation_1d /* [(2p+1) * (p+1)], fine index major, or NULL */,
+                          mfgpu_transfer **out);
+/* :595-627  dst_fine = P (src_coarse with the coarse Dirichlet dofs read as 0); every fine dof is written */
+int mfgpu_transfer_prolongate(mfgpu_transfer *t, void *dst_fine_dev, const void *src_coarse_dev, void *stream);
+/* :631-660  dst_coarse += P^T src_fine on the non-Dirichlet coarse dofs (floating-point atomics, as the reference) */
+int mfgpu_transfer_restrict_and_add(mfgpu_transfer *t, void *dst_coarse_dev, const void *src_fine_dev, void *stream);
+size_t mfgpu_transfer_memory_consumption(const mfgpu_transfer *t); /* :333-347 */
+void mfgpu_transfer_destroy(mfgpu_transfer *t);
+
 /* ---- deal.II stand-in for the setup side (host only) --------------------------------------
  * Produces what Triangulation + DoFHandler + ConstraintMatrix + FEValues + ShapeInfo hand to
  * MatrixFreeGpu::reinit, for the meshes bmop uses (bmop_common.h:108-120).                    */
@@ -242,6 +263,13 @@ int mfgpu_mesh_create_adaptive(int dim, int degree, int n_ref, int number_type, 
  * ball, 5 / 7 coarse cells), spherical manifold on the boundary, n_ref global refinements, MappingQ1.  Unstructured;
  * the description has a full J^-1 per quadrature point (no MFGPU_UNIFORM_J0).                                     */
 int mfgpu_mesh_create_ball(int dim, int degree, int n_ref, int number_type, mfgpu_mesh **out);
+/* MGTransferMatrixFreeGpu::build for two stand-in meshes (uniform cubes n and 2n cells per direction, or ball meshes
+ * of n_ref and n_ref + 1): the transfer between them, in the fine mesh's number type                               */
+int mfgpu_transfer_create_from_meshes(const mfgpu_mesh *coarse, const mfgpu_mesh *fine, mfgpu_transfer **out);
+/* the index arrays that call hands to mfgpu_transfer_create, on the host (no GPU needed): coarse_cell_dofs
+ * [n_cells * (p+1)^dim], fine_patch_dofs [n_cells * (2p+1)^dim], n_cells = the coarse mesh's; returns n_cells     */
+int64_t mfgpu_mesh_transfer_patches(const mfgpu_mesh *coarse, const mfgpu_mesh *fine, uint32_t *coarse_cell_dofs,
+                                    uint32_t *fine_patch_dofs);
 /* same setup from an explicit one-irregular set of octree leaves (level, cx, cy, cz) x n_leaves on
  * hyper_cube(-1,1): lets tests build the awkward small cases of test_hanging_nodes_gpu.cu:297-331 */
 int mfgpu_mesh_create_from_leaves(int dim, int degree, const uint32_t *leaves, uint32_t n_leaves,
