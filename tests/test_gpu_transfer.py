@@ -187,3 +187,28 @@ def test_multigrid_preconditioned_cg(dim, p, n0, nlev):
             xr = spla.spsolve(A, bh)
             assert np.linalg.norm(x.to_host() - xr) <= 1e-8 * np.linalg.norm(xr)
     assert iters[-1] <= 14 and iters[-1] <= iters[0] + 2, iters
+
+
+def test_poisson_mg_driver_binaries():
+    """C++ shim (mfgpu_shim_mg.h) + poisson_mg driver: CG + V-cycle to 1e-12, checked against the known solution;
+    line: dim degree n_dofs levels cg_iterations wall rel_error"""
+    import os
+    import subprocess
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    b = os.path.join(root, "dealii-cuda_amd", "host", "bin")
+    its = {}
+    for exe, arg, ndofs in (("poisson-mg-2d-p2", "5", 65 ** 2), ("poisson-mg-2d-p2", "7", 257 ** 2),
+                            ("poisson-mg-3d-p4", "3", 33 ** 3), ("poisson-mg-3d-p4", "4", 65 ** 3),
+                            ("poisson-mg-3d-p2-ball", "3", None)):
+        out = subprocess.run([os.path.join(b, exe), arg], capture_output=True, text=True, timeout=300)
+        assert out.returncode == 0, out.stdout + out.stderr
+        f = out.stdout.split()
+        if ndofs is not None:
+            assert int(f[2]) == ndofs
+        assert int(f[3]) == int(arg) + 1 and float(f[6]) < 1e-8
+        its[(exe, arg)] = int(f[4])
+    # level-independent iteration counts
+    assert its[("poisson-mg-2d-p2", "7")] <= its[("poisson-mg-2d-p2", "5")] + 2 <= 16
+    assert its[("poisson-mg-3d-p4", "4")] <= its[("poisson-mg-3d-p4", "3")] + 2 <= 16
+    assert its[("poisson-mg-3d-p2-ball", "3")] <= 30
