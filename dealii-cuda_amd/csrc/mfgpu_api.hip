@@ -363,6 +363,7 @@ int create_arrays(mfgpu_handle *h, const mfgpu_desc &d) {
     HIP_TRY(hipGetDevice(&dev));
     HIP_TRY(hipGetDeviceProperties(&prop, dev));
     h->max_grid_p = (uint32_t)(per_cu < 1 ? 1 : per_cu) * (uint32_t)prop.multiProcessorCount;
+    if (d.max_workgroups && d.max_workgroups < h->max_grid_p) h->max_grid_p = d.max_workgroups;
     if (!h->xk) {
       h->lds = lds_p;
       return 0;
@@ -405,6 +406,7 @@ int create_arrays(mfgpu_handle *h, const mfgpu_desc &d) {
   HIP_TRY(hipGetDevice(&dev));
   HIP_TRY(hipGetDeviceProperties(&prop, dev));
   h->max_grid = (uint32_t)(per_cu < 1 ? 1 : per_cu) * (uint32_t)prop.multiProcessorCount;
+  if (d.max_workgroups && d.max_workgroups < h->max_grid) h->max_grid = d.max_workgroups;
   return 0;
 }
 

@@ -34,7 +34,7 @@ class Desc(C.Structure):
         ("quadrature_points", C.c_void_p), ("shape_values", C.c_void_p), ("shape_gradients", C.c_void_p),
         ("constraint_weights", C.c_void_p), ("constrained_dofs", C.c_void_p),
         ("n_constrained", C.c_uint32), ("max_cells_per_batch", C.c_uint32), ("max_dofs_per_batch", C.c_uint32),
-        ("kernel", C.c_uint32), ("cell_loop_segments", C.c_uint32),
+        ("kernel", C.c_uint32), ("cell_loop_segments", C.c_uint32), ("max_workgroups", C.c_uint32),
     ]
 
 
@@ -256,7 +256,7 @@ class Mesh:
 def make_desc(dim, degree, n_dofs, loc2glob, JxW, inv_jac, coefficient, constrained,
               shape_values, shape_gradients, number_type=F64, constraint_mask=None,
               constraint_weights=None, quadrature_points=None, max_cells_per_batch=0, max_dofs_per_batch=0,
-              colored=False, kernel=0, cell_loop_segments=0):
+              colored=False, kernel=0, cell_loop_segments=0, max_workgroups=0):
     """Build a Desc from numpy arrays; returns (desc, keepalive list)."""
     dt = np_dtype(number_type)
     keep = []
@@ -294,6 +294,7 @@ def make_desc(dim, degree, n_dofs, loc2glob, JxW, inv_jac, coefficient, constrai
     d.max_dofs_per_batch = max_dofs_per_batch
     d.kernel = kernel
     d.cell_loop_segments = cell_loop_segments
+    d.max_workgroups = max_workgroups
     return d, keep
 
 

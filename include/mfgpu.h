@@ -97,6 +97,9 @@ typedef struct mfgpu_desc {
                                   ranges; the shared-dof sums (pass 2) a finished range completes run on a side
                                   stream of the handle, next to the following range's cells.  0 = the library's
                                   choice, 1 = one launch, pass 2 strictly after it                              */
+  uint32_t max_workgroups;     /* cap on the resident workgroups of the persistent cell-loop launches (0 = as many
+                                  as fit on the device): leaves room for other work on the GPU; also lets small
+                                  meshes exercise the multi-batch loop of a workgroup                          */
 } mfgpu_desc;
 
 /* mfgpu_desc.kernel (all variants compute the same operator; non-default ones exist for tests and measurements) */

@@ -91,3 +91,34 @@ def test_planes_unsupported_requests_fail_loudly():
     mesh.desc.kernel = mf.KERNEL_PLANES
     with pytest.raises(mf.MfgpuError):
         mf.Operator(mesh.desc, mesh)
+
+
+@pytest.mark.parametrize("p,n,wgs,kern,nt", [(4, 6, 1, mf.KERNEL_PLANES, mf.F64), (4, 7, 3, mf.KERNEL_PLANES, mf.F64),
+                                             (4, 9, 5, mf.KERNEL_PLANES, mf.F32), (4, 12, 9, mf.KERNEL_PLANES, mf.F64),
+                                             (3, 8, 3, mf.KERNEL_PLANES, mf.F64), (2, 9, 2, mf.KERNEL_PLANES, mf.F64),
+                                             (4, 6, 2, mf.KERNEL_PENCILS_X, mf.F64), (2, 9, 3, mf.KERNEL_PENCILS_X, mf.F64),
+                                             (6, 3, 1, mf.KERNEL_AUTO, mf.F64), (4, 5, 3, mf.KERNEL_PENCILS, mf.F64)])
+def test_few_workgroups_walk_many_batches(p, n, wgs, kern, nt):
+    """mfgpu_desc.max_workgroups: with a handful of workgroups on a small mesh every workgroup walks several batches,
+    i.e. the persistent loop with its loads one and two batches ahead and its deferred scatter, which small meshes
+    otherwise leave to the full-size property tests.  vmult, vmult_add and chained applies against the oracle."""
+    mesh = mf.Mesh.uniform(3, p, n, number_type=nt)
+    od = oracle_desc_from_mesh(mesh, dtype=np.float64)
+    mesh.desc.kernel = kern
+    mesh.desc.max_workgroups = wgs
+    mesh.desc.max_cells_per_batch = 0 if p == 4 else 8
+    op = mf.Operator(mesh.desc, mesh)
+    assert op.plan_stats()["n_batches"] >= 3 * wgs, op.plan_stats()
+    rng = np.random.default_rng(17 * n + wgs)
+    x, y0 = rng.standard_normal(mesh.n_dofs), rng.standard_normal(mesh.n_dofs)
+    xt, y0t = (v.astype(mf.np_dtype(nt)).astype(np.float64) for v in (x, y0))
+    assert rel(gpu_vmult(op, x, nt), o.vmult(od, xt)) <= TOL[nt]
+    assert rel(gpu_vmult(op, x, nt, y0=y0), o.vmult_add(od, y0t, xt)) <= TOL[nt]
+    if nt == mf.F64:
+        a, b = mf.DeviceVector(mesh.n_dofs), mf.DeviceVector(mesh.n_dofs)
+        b.fill(0.1)
+        for _ in range(3):
+            a, b = b, a
+            op.vmult(b, a)
+        mf.synchronize()
+        assert rel(b.to_host(), o.bmop_protocol(od, 3)) <= 1e-12 * 100 ** 2
