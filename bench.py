@@ -106,6 +106,10 @@ def main():
                          "(synthetic deformation F = h (I + EPS R), R random in [-1,1]); 1 GPU")
     ap.add_argument("--adaptive", type=int, default=0, metavar="NREF",
                     help="configs[2]: bmop -DADAPTIVE_GRID mesh with hanging nodes instead of the uniform cube (1 GPU)")
+    ap.add_argument("--renumber", action="store_true",
+                    help="second line, NOT the headline: renumber the mesh's dofs batch-major first (mfgpu_suggest_renumbering, "
+                         "the MatrixFree::renumber_dofs analogue); the reference and the default run keep the caller's numbering")
+    ap.add_argument("--no-second-line", action="store_true", help="skip the renumbered second line of the default run")
     ap.add_argument("--ball", type=int, default=-1, metavar="NREF",
                     help="bmop -DBALL_GRID: hyper_ball with NREF global refinements (unstructured, general-geometry path; 1 GPU)")
     args = ap.parse_args()
@@ -139,6 +143,12 @@ def main():
         mesh = mf.Mesh.adaptive(3, p, args.adaptive, number_type=nt)
     else:
         mesh = mf.Mesh.uniform(3, p, n_glob, slab=(zb, ze), number_type=nt)
+    if args.renumber:
+        if world != 1:
+            raise SystemExit("--renumber is a single-GPU measurement")
+        mesh.desc.max_cells_per_batch = args.batch_cells
+        mesh.desc.max_dofs_per_batch = args.batch_dofs
+        mesh.renumber(mesh.suggest_renumbering())
     mesh.desc.max_cells_per_batch = args.batch_cells
     mesh.desc.max_dofs_per_batch = args.batch_dofs
     mesh.desc.cell_loop_segments = args.segments
@@ -278,7 +288,7 @@ def main():
             if (tr.get("workload") == f"p{p}_3d_n{n_glob}_{'f32' if args.float else 'f64'}" and world == 1
                     and op.kernel_name() + "<" in tr.get("kernel", "") and tr.get("csrc_sha16") == csrc_sha16()
                     and not args.adaptive and not args.colored and not args.batch_cells and not args.batch_dofs
-                    and not general and args.kernel == "auto"):
+                    and not general and args.kernel == "auto" and not args.renumber):
                 traffic = tr["hbm_bytes_per_launch"]
                 traffic_source = {"file": "profiles/traffic_latest.json", "profile": tr.get("profile"),
                                   "csrc_sha16": tr.get("csrc_sha16")}
@@ -311,6 +321,7 @@ def main():
                                 f"{n_glob}^3 cells, {n_dofs_glob} DoFs, {world} z-slab(s)"),
                    "cells_per_dir": n_glob, "n_dofs": n_dofs_glob, "n_cells": n_cells_glob,
                    "parallelism": f"slab{world}" + (f"/{args.mode}" if world > 1 else ""),
+                   "dof_numbering": "batch-major (mfgpu_suggest_renumbering)" if args.renumber else "caller's (lexicographic)",
                    "plan": stats, "finite": finite},
         "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                      "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_source,
@@ -319,7 +330,7 @@ def main():
                      "alg_bytes_per_launch": b_alg_loc / stats["n_launches"],
                      "kernel_ms_per_vmult": k_ms / max(n_v, 1)},
     }
-    if rank == 0 and world == 1 and not args.no_cpu and not args.adaptive and not general:
+    if rank == 0 and world == 1 and not args.no_cpu and not args.adaptive and not general and not args.renumber:
         cb, n_cpu, y_cpu = cpu_baseline(args)
         out["cpu_baseline"] = cb
         if n_cpu == n_glob and not args.float:
@@ -330,6 +341,45 @@ def main():
             torch.cuda.synchronize()
             y_gpu = dst.cpu().numpy()
             out["gpu_vs_cpu_rel_l2"] = float(np.linalg.norm(y_gpu - y_cpu) / np.linalg.norm(y_cpu))
+    if (rank == 0 and world == 1 and not args.no_second_line and not args.renumber and not args.adaptive and not general
+            and not args.colored):
+        # SECOND line, not the headline: the same workload after the optional batch-major dof renumbering
+        # (mfgpu_suggest_renumbering, the MatrixFree::renumber_dofs analogue the reference does not use).  `value`
+        # above is measured in the caller's numbering.
+        try:
+            del op
+            mesh2 = mf.Mesh.uniform(3, p, n_glob, number_type=nt)
+            mesh2.desc.max_cells_per_batch, mesh2.desc.max_dofs_per_batch = args.batch_cells, args.batch_dofs
+            mesh2.renumber(mesh2.suggest_renumbering())
+            mesh2.desc.max_cells_per_batch, mesh2.desc.max_dofs_per_batch = args.batch_cells, args.batch_dofs
+            mesh2.desc.kernel = mesh.desc.kernel
+            op2 = mf.Operator(mesh2.desc, mesh2)
+            dst.fill_(0.1)
+            src.zero_()
+            for _ in range(args.warmup):
+                dst, src = src, dst
+                op2.vmult(dst, src, stream)
+            dst.mul_(0.1 / dst.abs().max())
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            for _ in range(args.steps):
+                dst, src = src, dst
+                op2.vmult(dst, src, stream)
+            torch.cuda.synchronize()
+            t2 = time.perf_counter() - t0
+            dst.mul_(0.1 / dst.abs().max())
+            op2.profile_enable(True)
+            for _ in range(min(args.steps, 20)):
+                dst, src = src, dst
+                op2.vmult(dst, src, stream)
+            k2, n2 = op2.profile_read()
+            out["second_line_renumbered"] = {
+                "note": "NOT the headline: same workload, dofs renumbered batch-major first (opt-in mfgpu_suggest_renumbering)",
+                "value": n_dofs_glob * args.steps / t2, "unit": "DoFs/s", "ms_per_step": 1e3 * t2 / args.steps,
+                "kernel_ms_per_vmult": k2 / max(n2, 1), "kernel": op2.kernel_name(),
+                "roofline_frac": b_alg_loc * n2 / (k2 * 1e-3) / 1e9 / HBM_PEAK_GBS}
+        except Exception as e:  # the second line must never cost the first
+            out["second_line_renumbered"] = {"error": str(e)}
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()

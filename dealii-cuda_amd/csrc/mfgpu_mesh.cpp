@@ -5,6 +5,7 @@
 //  * 1D tables: FE_Q(p) on Gauss-Lobatto support points, QGauss<1>(p+1) on [0,1]
 //  * uniform mesh: hyper_cube(lo,hi) with n cells per direction (bmop_common.h:119 generalised)
 //  * adaptive mesh: see mfgpu_mesh_adaptive.cpp
+#include <algorithm>
 #include <cmath>
 #include <cstring>
 
@@ -345,6 +346,35 @@ int mfgpu_mesh_create_uniform(int dim, int degree, const uint32_t *n_per_dir, do
 }
 
 void mfgpu_mesh_destroy(mfgpu_mesh *m) { delete m; }
+
+int mfgpu_mesh_renumber(mfgpu_mesh *m, const uint32_t *new_index) {
+  if (!m || !new_index) {
+    mfgpu::set_error("mfgpu_mesh_renumber: null argument");
+    return MFGPU_EINVAL;
+  }
+  mfgpu::Mesh &M = m->mesh;
+  const uint32_t N = M.n_dofs;
+  std::vector<uint8_t> seen(N, 0);
+  for (uint32_t g = 0; g < N; ++g) {
+    if (new_index[g] >= N || seen[new_index[g]]) {
+      mfgpu::set_error("mfgpu_mesh_renumber: not a permutation of the dofs");
+      return MFGPU_EINVAL;
+    }
+    seen[new_index[g]] = 1;
+  }
+  for (uint32_t &g : M.loc2glob) g = new_index[g];
+  for (uint32_t &g : M.constrained) g = new_index[g];
+  std::sort(M.constrained.begin(), M.constrained.end());  // the description wants an ascending list
+  for (int w = 0; w < 2; ++w)
+    for (uint32_t &g : M.iface[w]) g = new_index[g];  // (order kept: both neighbours agree on it)
+  const int dim = M.dim;
+  std::vector<double> xc(M.dof_coords.size());
+  for (uint32_t g = 0; g < N; ++g)
+    for (int d = 0; d < dim; ++d) xc[(size_t)new_index[g] * dim + d] = M.dof_coords[(size_t)g * dim + d];
+  M.dof_coords.swap(xc);
+  M.mg_kind = -1;  // the level-pair structure survives, but a renumbered level no longer matches its neighbours' patches
+  return 0;
+}
 
 int64_t mfgpu_mesh_transfer_patches(const mfgpu_mesh *coarse, const mfgpu_mesh *fine, uint32_t *coarse_cell_dofs,
                                     uint32_t *fine_patch_dofs) {

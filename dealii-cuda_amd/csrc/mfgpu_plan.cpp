@@ -600,6 +600,45 @@ int mfgpu_plan_create(const mfgpu_desc *desc, mfgpu_plan **out) {
 
 void mfgpu_plan_destroy(mfgpu_plan *p) { delete p; }
 
+int mfgpu_suggest_renumbering(const mfgpu_desc *desc, uint32_t *new_index) {
+  if (!desc || !new_index) {
+    mfgpu::set_error("null argument");
+    return MFGPU_EINVAL;
+  }
+  mfgpu::Plan P;
+  mfgpu::KernelChoice kc;
+  int rc = mfgpu::choose_kernel_and_plan(*desc, kc, P);
+  if (rc) return rc;
+  // batch-major: the dofs a batch owns alone, batch after batch (one contiguous run per batch: coalesced gathers and
+  // stores of the cell loop), then the dofs several batches share in the order pass 2 walks them (grouped by the set
+  // of batches: whole lines for pass 2 instead of isolated entries of a lexicographic numbering), then the dofs no
+  // cell touches
+  const uint32_t NONE = 0xffffffffu;
+  std::fill(new_index, new_index + desc->n_dofs, NONE);
+  uint32_t next = 0;
+  const size_t nb = P.batch_cell_off.size() - 1;
+  for (size_t b = 0; b < nb; ++b) {
+    const uint32_t d0 = P.batch_dof_off[b];
+    // coloured mode has no interior / shared split: a dof goes with the first batch that lists it
+    const uint32_t ni = P.batch_nint.empty() ? P.batch_dof_off[b + 1] - d0 : P.batch_nint[b];
+    for (uint32_t t = 0; t < ni; ++t) {
+      const uint32_t g = P.bdofs[d0 + t] & 0x7fffffffu;
+      if (new_index[g] == NONE) new_index[g] = next++;
+    }
+  }
+  for (uint32_t e : P.sdofs) {
+    const uint32_t g = e & 0x7fffffffu;
+    if (new_index[g] == NONE) new_index[g] = next++;
+  }
+  for (uint32_t g = 0; g < desc->n_dofs; ++g)
+    if (new_index[g] == NONE) new_index[g] = next++;
+  if (next != desc->n_dofs) {
+    mfgpu::set_error("internal: renumbering is not a permutation");
+    return MFGPU_EINVAL;
+  }
+  return 0;
+}
+
 int64_t mfgpu_plan_array_u32(const mfgpu_plan *p, int what, const uint32_t **ptr) {
   if (!p || !ptr) return MFGPU_EINVAL;
   const std::vector<uint32_t> *v = nullptr;

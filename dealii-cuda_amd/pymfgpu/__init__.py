@@ -53,7 +53,7 @@ SYMBOLS = [
     "mfgpu_vmult_dist_begin", "mfgpu_vmult_dist_end", "mfgpu_vmult_dist", "mfgpu_dist_destroy",
     "mfgpu_transfer_create", "mfgpu_transfer_create_from_meshes", "mfgpu_transfer_prolongate",
     "mfgpu_transfer_restrict_and_add", "mfgpu_transfer_memory_consumption", "mfgpu_transfer_destroy",
-    "mfgpu_mesh_transfer_patches",
+    "mfgpu_mesh_transfer_patches", "mfgpu_suggest_renumbering", "mfgpu_mesh_renumber",
 ]
 
 _lib = None
@@ -132,6 +132,8 @@ def lib():
         L.mfgpu_transfer_memory_consumption.restype = C.c_size_t
         L.mfgpu_mesh_transfer_patches.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
         L.mfgpu_mesh_transfer_patches.restype = C.c_int64
+        L.mfgpu_suggest_renumbering.argtypes = [C.POINTER(Desc), C.c_void_p]
+        L.mfgpu_mesh_renumber.argtypes = [C.c_void_p, C.c_void_p]
         L.mfgpu_transfer_destroy.argtypes = [C.c_void_p]
         L.mfgpu_transfer_destroy.restype = None
         _lib = L
@@ -236,6 +238,19 @@ class Mesh:
         p = C.c_void_p()
         cnt = lib().mfgpu_mesh_dof_coords(self._h, C.byref(p))
         return _view(p.value, cnt, np.float64).reshape(-1, self.desc.dim)
+
+    def suggest_renumbering(self):
+        """new_index[old] = new, batch-major for the operator's plan (mfgpu_suggest_renumbering); host only"""
+        out = np.zeros(self.n_dofs, dtype=np.uint32)
+        _check(lib().mfgpu_suggest_renumbering(C.byref(self.desc), out.ctypes.data))
+        return out
+
+    def renumber(self, new_index):
+        """DoFHandler::renumber_dofs on the stand-in mesh (in place); the desc pointers stay valid"""
+        ni = np.ascontiguousarray(new_index, dtype=np.uint32)
+        assert ni.size == self.n_dofs
+        _check(lib().mfgpu_mesh_renumber(self._h, ni.ctypes.data))
+        _check(lib().mfgpu_mesh_desc(self._h, C.byref(self.desc)))
 
     def transfer_patches(self, fine: "Mesh"):
         """(coarse_cell_dofs, fine_patch_dofs) of the level pair (self, fine): host arrays, no GPU"""

@@ -163,6 +163,13 @@ int64_t mfgpu_plan_array_u32(const mfgpu_plan *p, int what, const uint32_t **ptr
 int64_t mfgpu_plan_lmap(const mfgpu_plan *p, const uint16_t **ptr);   /* [n_cells*n^dim], plan order */
 int64_t mfgpu_plan_bflags(const mfgpu_plan *p, const uint8_t **ptr);  /* bit0 constrained, bit1 add */
 
+/* ---- optional: a dof numbering that suits the operator (deal.II's MatrixFree::renumber_dofs; the reference does not
+ * renumber, and nothing here requires it).  new_index[old dof] = new dof, batch-major: the dofs of a batch are one
+ * contiguous run (coalesced gathers and stores of the cell loop), the dofs shared between batches follow in the order
+ * pass 2 walks them.  The caller renumbers ITS DoFHandler (DoFHandler::renumber_dofs; stand-in: mfgpu_mesh_renumber)
+ * and describes the renumbered mesh to mfgpu_create; vectors then live in the new numbering.  Host only.          */
+int mfgpu_suggest_renumbering(const mfgpu_desc *desc, uint32_t *new_index /* [n_dofs] */);
+
 /* ---- what a CG / Chebyshev caller needs from the operator besides vmult -------------
  * LaplaceOperatorGpu::compute_diagonal + get_diagonal_inverse (laplace_operator_gpu.h:401-429): writes
  * 1 / diag(A) into inv_diag[n_dofs] (device, operator's number type); the local diagonal of every cell
@@ -273,6 +280,8 @@ int mfgpu_transfer_create_from_meshes(const mfgpu_mesh *coarse, const mfgpu_mesh
  * [n_cells * (p+1)^dim], fine_patch_dofs [n_cells * (2p+1)^dim], n_cells = the coarse mesh's; returns n_cells     */
 int64_t mfgpu_mesh_transfer_patches(const mfgpu_mesh *coarse, const mfgpu_mesh *fine, uint32_t *coarse_cell_dofs,
                                     uint32_t *fine_patch_dofs);
+/* DoFHandler::renumber_dofs on the stand-in: loc2glob, constrained dofs, dof coordinates, interface planes */
+int mfgpu_mesh_renumber(mfgpu_mesh *m, const uint32_t *new_index);
 /* same setup from an explicit one-irregular set of octree leaves (level, cx, cy, cz) x n_leaves on
  * hyper_cube(-1,1): lets tests build the awkward small cases of test_hanging_nodes_gpu.cu:297-331 */
 int mfgpu_mesh_create_from_leaves(int dim, int degree, const uint32_t *leaves, uint32_t n_leaves,

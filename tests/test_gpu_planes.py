@@ -122,3 +122,26 @@ def test_few_workgroups_walk_many_batches(p, n, wgs, kern, nt):
             op.vmult(b, a)
         mf.synchronize()
         assert rel(b.to_host(), o.bmop_protocol(od, 3)) <= 1e-12 * 100 ** 2
+
+
+@pytest.mark.parametrize("make,kern", [(lambda: mf.Mesh.uniform(3, 4, 7), 0), (lambda: mf.Mesh.uniform(3, 2, 9), 0),
+                                       (lambda: mf.Mesh.uniform(2, 4, 9), 0), (lambda: mf.Mesh.adaptive(3, 4, 4), 0),
+                                       (lambda: mf.Mesh.ball(3, 2, 2), 0)])
+def test_renumbered_mesh_gives_the_same_operator(make, kern):
+    """optional batch-major dof numbering (mfgpu_suggest_renumbering + mfgpu_mesh_renumber): y_new[new(i)] = y_old[i]"""
+    mesh = make()
+    od0 = oracle_desc_from_mesh(mesh)
+    x0 = np.random.default_rng(3).standard_normal(mesh.n_dofs)
+    y0 = gpu_vmult(mf.Operator(mesh.desc, mesh), x0)
+    assert rel(y0, o.vmult(od0, x0)) <= 1e-12
+    ni = mesh.suggest_renumbering()
+    mesh.renumber(ni)
+    od1 = oracle_desc_from_mesh(mesh)
+    x1 = np.empty_like(x0)
+    x1[ni] = x0
+    op = mf.Operator(mesh.desc, mesh)
+    y1 = gpu_vmult(op, x1)
+    assert rel(y1, o.vmult(od1, x1)) <= 1e-12
+    assert rel(y1[ni], y0) <= 1e-12
+    z = np.random.default_rng(4).standard_normal(mesh.n_dofs)
+    assert rel(gpu_vmult(op, x1, y0=z), o.vmult_add(od1, z, x1)) <= 1e-12

@@ -12,6 +12,6 @@ if [ "$1" = build ]; then
 else
   for N in 0 1 2 4 7; do
     L=$R/dealii-cuda_amd/lib/libmfgpu_abl$N.so; [ $N = 0 ] && L=$R/dealii-cuda_amd/lib/libmfgpu.so
-    echo -n "ABL=$N  "; MFGPU_LIB=$L python3 $R/bench.py --steps 30 --warmup 3 --no-cpu 2>&1 | tail -1 | grep -o "avg_launch_us[^,]*"
+    echo -n "ABL=$N  "; MFGPU_LIB=$L python3 $R/bench.py --steps 30 --warmup 3 --no-cpu --no-second-line 2>&1 | tail -1 | grep -o "avg_launch_us[^,]*"
   done
 fi

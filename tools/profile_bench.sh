@@ -8,7 +8,7 @@ R=${GRAFT_REPO_ROOT:-/root/repo}
 TAG=${1:-r01}; shift
 O=$R/gpurun_out/$TAG
 mkdir -p $O
-B="python3 $R/bench.py --steps 20 --warmup 3 --no-cpu $@"
+B="python3 $R/bench.py --steps 20 --warmup 3 --no-cpu --no-second-line $@"
 timeout -k 5 300 rocprofv3 --kernel-trace --stats --output-format csv -d $O/kt -- $B > $O/kt.log 2>&1; echo "kt rc=$?"
 timeout -k 5 300 rocprofv3 --pmc FETCH_SIZE --output-format csv -d $O/fetch -- $B > $O/fetch.log 2>&1; echo "fetch rc=$?"
 timeout -k 5 300 rocprofv3 --pmc WRITE_SIZE --output-format csv -d $O/write -- $B > $O/write.log 2>&1; echo "write rc=$?"

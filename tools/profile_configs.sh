@@ -6,8 +6,8 @@ R=${GRAFT_REPO_ROOT:-/root/repo}
 TAG=${1:-r02}
 run() {  # name, bench args...
   local name=$1; shift
-  python3 $R/bench.py --steps 50 --warmup 5 --no-cpu "$@" 2>/dev/null | tail -1 > $R/gpurun_out/${TAG}_${name}_line.json
-  timeout -k 5 300 rocprofv3 --kernel-trace --stats --output-format csv -d $R/gpurun_out/${TAG}_${name}_kt -- python3 $R/bench.py --steps 20 --warmup 3 --no-cpu "$@" > $R/gpurun_out/${TAG}_${name}_kt.log 2>&1
+  python3 $R/bench.py --steps 50 --warmup 5 --no-cpu --no-second-line "$@" 2>/dev/null | tail -1 > $R/gpurun_out/${TAG}_${name}_line.json
+  timeout -k 5 300 rocprofv3 --kernel-trace --stats --output-format csv -d $R/gpurun_out/${TAG}_${name}_kt -- python3 $R/bench.py --steps 20 --warmup 3 --no-cpu --no-second-line "$@" > $R/gpurun_out/${TAG}_${name}_kt.log 2>&1
   cp $(ls $R/gpurun_out/${TAG}_${name}_kt/*/*kernel_stats.csv | head -1) $R/gpurun_out/${TAG}_${name}_kernel_stats.csv
   echo "$name done: $(cut -c1-200 $R/gpurun_out/${TAG}_${name}_line.json | grep -o '"ms_per_step": [0-9.]*')"
 }
