@@ -11,9 +11,17 @@ def oracle_desc_from_mesh(mesh: "mf.Mesh", dtype=None) -> o.Desc:
     d = mesh.desc
     dt = mf.np_dtype(d.number_type) if dtype is None else dtype
     coef = o.coefficient_value(a["quadrature_points"].astype(np.float64))
+    # The 1D tables and hanging-node weights are the ORACLE's own (oracle/mf_oracle.py shape_info / constraint_weights,
+    # checked there against the published GLL / Gauss values), not the product's: the product's copies are compared
+    # with them here, so a wrong table in the mesh stand-in cannot cancel out of a GPU-vs-oracle comparison.
+    sv, sg, _, _, _ = o.shape_info(d.degree)
+    w = o.constraint_weights(d.degree)
+    tol = 1e-13 if d.number_type == mf.F64 else 1e-6
+    assert np.abs(a["shape_values"].astype(np.float64).reshape(sv.shape) - sv).max() <= tol
+    assert np.abs(a["shape_gradients"].astype(np.float64).reshape(sg.shape) - sg).max() <= tol * max(1.0, np.abs(sg).max())
+    assert np.abs(a["constraint_weights"].reshape(w.shape) - w).max() <= 1e-13
     return o.Desc(d.dim, d.degree, d.n_dofs, a["loc2glob"], a["JxW"], a["inv_jac"], coef,
-                  a["constrained_dofs"], a["constraint_mask"], dt, a["shape_values"], a["shape_gradients"],
-                  a["constraint_weights"], mesh.dof_coords())
+                  a["constrained_dofs"], a["constraint_mask"], dt, sv, sg, w, mesh.dof_coords())
 
 
 def desc_from_oracle(od: o.Desc, number_type=mf.F64, **kw):
