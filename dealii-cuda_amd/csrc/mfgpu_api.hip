@@ -35,6 +35,7 @@ struct mfgpu_handle {
   uint16_t *d_perm = nullptr;  // apply_batches_x: bank-conflict-free lane -> pencil maps of the y- and z-stage
   // apply_planes3: fixed-size per-batch records (see ApplyArgs)
   uint32_t *d_bdofsp = nullptr, *d_idxp = nullptr;
+  uint32_t *d_hnhdr = nullptr, *d_hncopy = nullptr, *d_hnops = nullptr;  // apply_planes3<HN>: per-batch line operations
   void *d_coefp = nullptr;
   void *d_coef = nullptr;
   uint32_t *d_cmask = nullptr, *d_orphans = nullptr;
@@ -64,6 +65,7 @@ struct mfgpu_handle {
   size_t lds = 0, device_bytes = 0;
   uint32_t max_grid = 0;    // resident workgroups of the cell-loop kernel
   uint32_t max_grid_p = 0;  // ... of apply_planes3 (its batches: the first plan.n_plane_batches)
+  uint32_t max_grid_ph = 0;  // ... of apply_planes3<HN> (the plane batches of cells with a hanging-node mask)
   bool xk = false;        // 3D two-pass kernel for three workgroups per CU (apply_batches_x)
   bool gk = false;        // general-Jacobian kernel (apply_batches_g)
   bool pk = false;        // plane-per-thread kernel (apply_planes3): 3D uniform-Jacobian default for p = 2..4
@@ -231,6 +233,16 @@ int create_arrays(mfgpu_handle *h, const mfgpu_desc &d) {
     const uint32_t dummy = 8u * (uint32_t)(NB - 1);
     std::vector<uint32_t> bd((size_t)NB * nbat), ix((size_t)NIW * NT * nbat, dummy | (dummy << 16));
     std::vector<uint32_t> slot_of;  // batch-local id (position in P.bdofs) -> slot
+    // batches of cells WITH a hanging-node mask (apply_planes3<HN>, the plan's batches n_plain_plane_batches ..): the
+    // constrained nodes of a cell (those on a line one of the interpolation passes of hanging_nodes.cuh:617-696
+    // touches) get PRIVATE positions behind the dof list; the cell's index runs point there.  Per batch: a copy list
+    // (private position <- position of the node's dof in the list) and per direction the line operations, each the n
+    // private positions of a line in the order the plain weight matrix applies to (hn_cell_lines).
+    std::vector<uint32_t> hnhdr, hncopy, hnops;
+    std::vector<HnLine> lines[3];
+    std::vector<uint16_t> pnodes;
+    std::vector<uint32_t> priv_pos((size_t)P.nd);
+    const uint32_t npl_plain = P.n_plain_plane_batches;
     for (size_t b = 0; b < nbat; ++b) {
       const uint32_t c0 = P.batch_cell_off[b], nc = P.batch_cell_off[b + 1] - c0;
       const uint32_t d0 = P.batch_dof_off[b], nbd = P.batch_dof_off[b + 1] - d0, ni = P.batch_nint[b];
@@ -246,13 +258,55 @@ int create_arrays(mfgpu_handle *h, const mfgpu_desc &d) {
         else src_t = std::min<uint32_t>(ni + (uint32_t)(t - JI), nbd - 1);
         bd[b * NB + t] = P.bdofs[d0 + src_t];
       }
-      for (uint32_t c = 0; c < nc; ++c)
+      const bool hnb = b >= npl_plain;
+      uint32_t next_priv = (uint32_t)NB;
+      uint32_t hdr[8] = {(uint32_t)hncopy.size(), 0u, (uint32_t)(hnops.size() / 4), 0u, 0u, 0u, 0u, 0u};
+      std::vector<uint32_t> ops_d[3];
+      for (uint32_t c = 0; c < nc; ++c) {
+        const unsigned mask = hnb ? d.constraint_mask[P.cell_order[c0 + c]] : 0u;
+        std::fill(priv_pos.begin(), priv_pos.end(), 0xffffffffu);
+        if (mask) {
+          hn_cell_lines(mask, n, lines, pnodes);
+          for (uint16_t node : pnodes) {
+            if (next_priv >= (uint32_t)NB + (uint32_t)p_priv_max(n)) {
+              set_error("internal: batch exceeds the plane kernel's private hanging-node entries");
+              return MFGPU_EINVAL;
+            }
+            priv_pos[node] = next_priv;
+            hncopy.push_back((next_priv << 16) | slot_of[P.lmap[(size_t)(c0 + c) * P.nd + node]]);
+            ++next_priv;
+          }
+          for (int dir = 0; dir < 3; ++dir)
+            for (const HnLine &L : lines[dir]) {
+              uint32_t w[4] = {0u, 0u, 0u, 0u};
+              for (int t = 0; t < n; ++t) w[t >> 1] |= priv_pos[L.node[t]] << (16 * (t & 1));
+              ops_d[dir].insert(ops_d[dir].end(), w, w + 4);
+            }
+        }
         for (int k = 0; k < n; ++k)
           for (int i = 0; i < n2; ++i) {
-            const uint32_t off = 8u * slot_of[P.lmap[(size_t)(c0 + c) * P.nd + i + n2 * k]];
+            const int node = i + n2 * k;
+            const uint32_t pos = priv_pos[node] != 0xffffffffu ? priv_pos[node] : slot_of[P.lmap[(size_t)(c0 + c) * P.nd + node]];
+            const uint32_t off = 8u * pos;
             uint32_t &w = ix[(b * NIW + i / 2) * NT + c * n + k];
             w = (i & 1) ? ((w & 0xffffu) | (off << 16)) : ((w & 0xffff0000u) | off);
           }
+      }
+      if (hnb) {
+        hdr[1] = (uint32_t)hncopy.size() - hdr[0];
+        for (int dir = 0; dir < 3; ++dir) {
+          hdr[3 + dir] = (uint32_t)(ops_d[dir].size() / 4);
+          hnops.insert(hnops.end(), ops_d[dir].begin(), ops_d[dir].end());
+        }
+        hnhdr.insert(hnhdr.end(), hdr, hdr + 8);
+      }
+    }
+    if (!hnhdr.empty()) {
+      hncopy.push_back(0u);  // (never empty)
+      hnops.resize(hnops.size() + 4, 0u);
+      if ((rc = dev_upload(&h->d_hnhdr, hnhdr.data(), hnhdr.size() * 4, acct))) return rc;
+      if ((rc = dev_upload(&h->d_hncopy, hncopy.data(), hncopy.size() * 4, acct))) return rc;
+      if ((rc = dev_upload(&h->d_hnops, hnops.data(), hnops.size() * 4, acct))) return rc;
     }
     if ((rc = dev_upload(&h->d_bdofsp, bd.data(), bd.size() * 4, acct))) return rc;
     if ((rc = dev_upload(&h->d_idxp, ix.data(), ix.size() * 4, acct))) return rc;
@@ -359,7 +413,19 @@ int create_arrays(mfgpu_handle *h, const mfgpu_desc &d) {
     int per_cu = 0, dev = 0;
     hipDeviceProp_t prop;
     size_t lds_p = 0;
-    HIP_TRY(p_launch<T>(P.n, dummy, nullptr, nullptr, 0, nullptr, true, &lds_p, &per_cu));
+    HIP_TRY(p_launch<T>(P.n, dummy, nullptr, nullptr, false, 0, nullptr, true, &lds_p, &per_cu));
+    if (P.n_plain_plane_batches < P.n_plane_batches) {  // batches of masked cells: apply_planes3<HN>
+      int per_cu_h = 0;
+      size_t lds_h = 0;
+      HIP_TRY(p_launch<T>(P.n, dummy, nullptr, nullptr, true, 0, nullptr, true, &lds_h, &per_cu_h));
+      hipDeviceProp_t prop_h;
+      int dev_h = 0;
+      HIP_TRY(hipGetDevice(&dev_h));
+      HIP_TRY(hipGetDeviceProperties(&prop_h, dev_h));
+      h->max_grid_ph = (uint32_t)(per_cu_h < 1 ? 1 : per_cu_h) * (uint32_t)prop_h.multiProcessorCount;
+      if (d.max_workgroups && d.max_workgroups < h->max_grid_ph) h->max_grid_ph = d.max_workgroups;
+      if (lds_h > lds_p) lds_p = lds_h;
+    }
     HIP_TRY(hipGetDevice(&dev));
     HIP_TRY(hipGetDeviceProperties(&prop, dev));
     h->max_grid_p = (uint32_t)(per_cu < 1 ? 1 : per_cu) * (uint32_t)prop.multiProcessorCount;
@@ -423,9 +489,10 @@ void choose_segments(mfgpu_handle *h, uint32_t request) {
   const uint32_t nb = (uint32_t)(P.batch_cell_off.size() - 1);
   h->seg_end.assign(1, nb);
   if (!h->twopass || nb < 2 || request == 1) return;
-  const uint32_t npl = h->pk ? P.n_plane_batches : 0u;
+  const uint32_t npl = h->pk ? P.n_plane_batches : 0u, nplain = h->pk ? P.n_plain_plane_batches : 0u;
   std::vector<uint32_t> cuts;
   if (npl > 0 && npl < nb) cuts.push_back(npl);
+  if (nplain > 0 && nplain < npl) cuts.push_back(nplain);  // plain plane batches | plane batches of masked cells
   if (request > 1) {
     for (uint32_t i = 1; i < request; ++i) cuts.push_back((uint32_t)((uint64_t)nb * i / request));
   }
@@ -482,12 +549,21 @@ template <typename T>
 int launch_cells(mfgpu_handle *h, ApplyArgs<T> a, uint32_t b0, uint32_t b1, hipStream_t st) {
   const Plan &P = h->plan;
   const uint32_t npl = h->pk ? P.n_plane_batches : 0u;
-  if (b0 < npl) {  // the batches of cells without a hanging-node mask (all batches on conforming meshes)
+  const uint32_t nplain = h->pk ? P.n_plain_plane_batches : 0u;
+  if (b0 < nplain) {  // the batches of cells without a hanging-node mask (all batches on conforming meshes)
+    a.batch0 = b0;
+    a.batch_end = b1 < nplain ? b1 : nplain;
+    const uint32_t nbat = a.batch_end - a.batch0;
+    HIP_TRY(p_launch<T>(P.n, a, h->S.data(), h->Dt.data(), false, nbat < h->max_grid_p ? nbat : h->max_grid_p, st,
+                        false, nullptr, nullptr));
+    b0 = a.batch_end;
+  }
+  if (b0 < npl && b0 < b1) {  // plane batches of cells WITH a mask
     a.batch0 = b0;
     a.batch_end = b1 < npl ? b1 : npl;
     const uint32_t nbat = a.batch_end - a.batch0;
-    HIP_TRY(p_launch<T>(P.n, a, h->S.data(), h->Dt.data(), nbat < h->max_grid_p ? nbat : h->max_grid_p, st, false,
-                        nullptr, nullptr));
+    HIP_TRY(p_launch<T>(P.n, a, h->S.data(), h->Dt.data(), true, nbat < h->max_grid_ph ? nbat : h->max_grid_ph, st,
+                        false, nullptr, nullptr));
     b0 = a.batch_end;
   }
   if (b0 >= b1) return 0;
@@ -518,6 +594,10 @@ int vmult_main(mfgpu_handle *h, void *dst, const void *src, hipStream_t st, int 
   a.perm = h->d_perm;
   a.bdofsp = h->d_bdofsp;
   a.idxp = h->d_idxp;
+  a.hnhdr = h->d_hnhdr;
+  a.hncopy = h->d_hncopy;
+  a.hnops = reinterpret_cast<const uint4 *>(h->d_hnops);
+  a.hn_batch0 = P.n_plain_plane_batches;
   a.coefp = (const T *)h->d_coefp;
   a.coef = (const T *)h->d_coef;
   a.cmask = h->d_cmask;
@@ -756,6 +836,9 @@ void mfgpu_destroy(mfgpu_handle *h) {
   hipFree(h->d_perm);
   hipFree(h->d_bdofsp);
   hipFree(h->d_idxp);
+  hipFree(h->d_hnhdr);
+  hipFree(h->d_hncopy);
+  hipFree(h->d_hnops);
   hipFree(h->d_coefp);
   hipFree(h->d_constrained);
   hipFree(h->d_tab2);

@@ -59,6 +59,12 @@ MFGPU_HD inline void p_wg_range(uint32_t nbt, uint32_t G, uint32_t wg, uint32_t 
 }
 constexpr uint32_t kCarryBit = 1u << 30;  // dof-list entry of apply_planes3: the partial sum is carried to the next batch
 
+// apply_planes3 on cells WITH a hanging-node mask: the constrained nodes of a cell get PRIVATE entries behind the
+// batch's dof list (p_priv_max(n) of them per batch), a copy of the gathered values, on which the 1D interpolation
+// passes of resolve_hanging_nodes (hanging_nodes.cuh:617-696) run line by line before the cell stages, and their
+// transposes after them (mfgpu_plan.cpp hn_cell_lines, mfgpu_kernels_p.hip)
+constexpr int p_priv_max(int n) { return n == 5 ? 384 : n == 4 ? 256 : 192; }
+
 constexpr uint8_t kFlagConstrained = 1;  // batch dof is a constrained row (identity)
 constexpr uint8_t kFlagAdd = 2;          // batch is NOT the first toucher: dst += (else dst =)
 
@@ -88,6 +94,7 @@ struct Plan {
   std::vector<uint32_t> gstarts;          // per group: halo slot of its first dof in each of its k touchers
   uint32_t max_batch_dofs = 0, max_batch_cells = 0;
   uint32_t n_plane_batches = 0;  // the first n_plane_batches batches run in apply_planes3, the rest in apply_batches_x
+  uint32_t n_plain_plane_batches = 0;  // ... of which the first n_plain_plane_batches hold cells without a mask only
   uint64_t n_first = 0, n_add = 0;
 };
 
@@ -102,11 +109,25 @@ struct PlanLimits {
   // meshes with hanging nodes: batches of unmasked cells only (plane kernel) first, then batches of masked cells
   // under the pencil kernel's limits (see build_plan)
   bool segregate_masked = false;
+  // ... or, with masked_planes, also as plane batches (apply_planes3<HN>): same slot structure, and at most
+  // private_max private entries per batch for the cells' constrained nodes
+  bool masked_planes = false;
+  uint32_t private_max = 0;
 };
 
 // Build the plan from a description (validates it).  Returns 0 or MFGPU_E*.
 // max_chunks: chunks of cells per batch the cell-loop kernel unrolls (3; apply_batches_x at p=3: 4)
 int build_plan(const mfgpu_desc &d, Plan &plan, uint32_t max_chunks = 3, const PlanLimits *limits = nullptr);
+
+// The line operations of interpolate_boundary_3d (hanging_nodes.cuh:617-696) for one cell mask: per direction d
+// (passes run in the order x, y, z) the flagged lines, each as its n local node ids (x + n y + n^2 z) listed in the
+// order in which the PLAIN weight matrix W applies to them -- ascending along d where the mask's type bit of d is set,
+// descending otherwise (W reversed in both indices == W on the reversed line).  nodes: every local node on a flagged
+// line, ascending.
+struct HnLine {
+  uint16_t node[8];
+};
+void hn_cell_lines(unsigned mask, int n, std::vector<HnLine> (&lines)[3], std::vector<uint16_t> &nodes);
 
 // Which cell-loop kernel family serves a description (mfgpu_desc.kernel; 0 = the library's choice), and the plan
 // built for it -- shared by mfgpu_create and the host-only mfgpu_plan_create:

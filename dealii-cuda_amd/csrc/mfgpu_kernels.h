@@ -21,6 +21,11 @@ struct ApplyArgs {
   const uint32_t *bdofsp;  // [p_kgu(n) * 64] dof list: p_ji(n) slots of interior dofs, p_hs(n) slots of pass-2 dofs
   const uint32_t *idxp;    // [(n*n+1)/2 words][NT tasks] packed 16-bit byte offsets into the batch array
   const T *coefp;          // [n*n rows][NT tasks] folded coefficient
+  // apply_planes3<HN> (batches hn_batch0 ..): per batch {copy offset, copies, first line op, ops x, ops y, ops z, -, -},
+  // copies (private position << 16 | dof-list position), line ops (n private positions, 16 bit each, in a uint4)
+  const uint32_t *hnhdr, *hncopy;
+  const uint4 *hnops;
+  uint32_t hn_batch0;
   const T *coef;          // folded a*J0^2*JxW (apply_batches_g: the 6 entries of a*JxW*J*J^T), plan cell order
   const uint32_t *cmask;  // plan cell order, or nullptr
   const T *hn_weights;    // [n*n] W[i*n+j] (device), or nullptr
@@ -66,8 +71,8 @@ hipError_t x_launch(int n, const ApplyArgs<T> &a, const double *S, const double 
                     hipStream_t st, bool configure_only, size_t *lds_out, int *occupancy);
 // plane-per-thread cell loop (mfgpu_kernels_p.hip; 3D, two-pass mode, uniform-Jacobian path) and its setup relayout
 template <typename T>
-hipError_t p_launch(int n, const ApplyArgs<T> &a, const double *S, const double *Dt, uint32_t grid, hipStream_t st,
-                    bool configure_only, size_t *lds_out, int *occupancy);
+hipError_t p_launch(int n, const ApplyArgs<T> &a, const double *S, const double *Dt, bool hn, uint32_t grid,
+                    hipStream_t st, bool configure_only, size_t *lds_out, int *occupancy);
 template <typename T>
 hipError_t relayout_coef_launch(T *out, const T *in, const uint32_t *cell_batch, const uint32_t *cell_pos,
                                 size_t total, int n, hipStream_t st);

@@ -142,7 +142,13 @@ __device__ __forceinline__ void eo_apply(const TablesEO<T, n> &tb, const T (&in)
 // scheduler would otherwise issue all of them first), while the next step's LDS reads may still be hoisted
 #define MFGPU_PIN_VMEM() __builtin_amdgcn_sched_barrier(0x380)
 
-template <int n, typename T, bool ADD>
+// HN: the batches of cells WITH a hanging-node mask.  The cells' constrained nodes have private entries behind the
+// batch array's dof-list part (mfgpu_api.hip); on them the interpolation passes of resolve_hanging_nodes
+// (hanging_nodes.cuh:617-696: along x, then y, then z, one flagged line per lane) run before stage A, and the
+// transposed passes in reverse order (the exact adjoint) after stage C, each line as a plain n x n mat-vec with the
+// weight matrix W (a line of a cell whose type bit is clear is listed in reverse, which mirrors W).  The cell stages
+// themselves do not know about hanging nodes.
+template <int n, typename T, bool ADD, bool HN>
 __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(1, 1)))
 apply_planes3(const ApplyArgs<T> A, const TablesEO<T, n> tab) {
   constexpr int n2 = n * n;
@@ -154,11 +160,16 @@ apply_planes3(const ApplyArgs<T> A, const TablesEO<T, n> tab) {
   constexpr int SA = p_cell_stride(n);     // padded cell stride of the transpose arrays
   constexpr int NIW = (n2 + 1) / 2;        // 32-bit words of a task's packed index run
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+  constexpr int PRIV = HN ? p_priv_max(n) : 0;        // private entries of the hanging-node batches
   double *ua = reinterpret_cast<double *>(smem_raw);  // gathered source values, then the accumulator
-  T *Aw = reinterpret_cast<T *>(ua + KGU * 64);       // CW cells + one scratch cell for the idle lanes
+  T *Aw = reinterpret_cast<T *>(ua + KGU * 64 + PRIV + (HN ? n2 : 0));  // CW cells + one scratch cell for the idle lanes
   T *Bw = Aw + (CW + 1) * SA;
+  double *Wl = ua + KGU * 64 + PRIV;  // HN: the weight matrix W[i * n + k] (hanging_nodes.cuh:580-598)
 
   const int lane = threadIdx.x;
+  if (HN) {
+    if (lane < n2) Wl[lane] = (double)A.hn_weights[lane];
+  }
   // The idle lanes (NT .. 63) and the tasks of cells a ragged batch does not have run the same instruction stream on
   // harmless data: the idle lanes own a scratch cell of the transpose arrays, a missing task's coefficient rows are
   // zero and its index run points at the batch array's last slot (never a dof: mfgpu_api.hip); only the adds into
@@ -279,6 +290,54 @@ apply_planes3(const ApplyArgs<T> A, const TablesEO<T, n> tab) {
 
   while (true) {
     const bool has_next = b1 != b;
+    // ---- hanging-node batches: private copies of the constrained nodes, then the interpolation passes x, y, z
+    uint32_t hn_copy0 = 0, hn_ncopy = 0, hn_op0 = 0, hn_nx = 0, hn_ny = 0, hn_nz = 0;
+    auto hn_pass = [&](uint32_t first, uint32_t count, bool transposed) {
+      for (uint32_t e0 = 0; e0 < count; e0 += 64) {  // (uniform trip count)
+        const uint32_t e = e0 + (uint32_t)lane;
+        const bool on = e < count;
+        const uint4 w = A.hnops[first + (on ? e : 0u)];
+        const uint32_t ww[4] = {w.x, w.y, w.z, w.w};
+        double v[n], o[n];
+        uint32_t pos[n];
+#pragma unroll
+        for (int t = 0; t < n; ++t) {
+          pos[t] = (ww[t >> 1] >> (16 * (t & 1))) & 0xffffu;
+          v[t] = ua[pos[t]];
+        }
+#pragma unroll
+        for (int i = 0; i < n; ++i) {
+          double acc = 0.0;
+#pragma unroll
+          for (int k2 = 0; k2 < n; ++k2) acc = fma(transposed ? Wl[k2 * n + i] : Wl[i * n + k2], v[k2], acc);
+          o[i] = acc;
+        }
+        if (on) {
+#pragma unroll
+          for (int i = 0; i < n; ++i) ua[pos[i]] = o[i];
+        }
+      }
+    };
+    if (HN) {
+      const uint32_t *hd = A.hnhdr + (size_t)(b - A.hn_batch0) * 8;
+      hn_copy0 = __builtin_amdgcn_readfirstlane(hd[0]);
+      hn_ncopy = __builtin_amdgcn_readfirstlane(hd[1]);
+      hn_op0 = __builtin_amdgcn_readfirstlane(hd[2]);
+      hn_nx = __builtin_amdgcn_readfirstlane(hd[3]);
+      hn_ny = __builtin_amdgcn_readfirstlane(hd[4]);
+      hn_nz = __builtin_amdgcn_readfirstlane(hd[5]);
+      for (uint32_t e = (uint32_t)lane; e < hn_ncopy; e += 64) {
+        const uint32_t w = A.hncopy[hn_copy0 + e];
+        ua[w >> 16] = ua[w & 0xffffu];
+      }
+      WaveSync::sync();
+      hn_pass(hn_op0, hn_nx, false);
+      WaveSync::sync();
+      hn_pass(hn_op0 + hn_nx, hn_ny, false);
+      WaveSync::sync();
+      hn_pass(hn_op0 + hn_nx + hn_ny, hn_nz, false);
+      WaveSync::sync();
+    }
     STAMP(0);
     RSTAMP(8);
 #ifdef MFGPU_STAMPS
@@ -362,7 +421,7 @@ apply_planes3(const ApplyArgs<T> A, const TablesEO<T, n> tab) {
     STAMP(2);
     // every gather of the batch is done: the array becomes the accumulator
 #pragma unroll
-    for (int j = 0; j < KGU; ++j) ua[lane + j * 64] = 0.0;
+    for (int j = 0; j < KGU + PRIV / 64; ++j) ua[lane + j * 64] = 0.0;
 
     // ---- stage B: plane (y, z) at quadrature index x = k.  The LDS reads of a line are issued one step ahead of
     // its contractions (a lone wave per SIMD has nothing else to cover the LDS latency with).
@@ -486,6 +545,20 @@ apply_planes3(const ApplyArgs<T> A, const TablesEO<T, n> tab) {
     WaveSync::sync();
     STAMP(4);
 
+    if (HN) {
+      // the transposed passes in reverse order, then the private entries' sums go to their dofs' entries
+      hn_pass(hn_op0 + hn_nx + hn_ny, hn_nz, true);
+      WaveSync::sync();
+      hn_pass(hn_op0 + hn_nx, hn_ny, true);
+      WaveSync::sync();
+      hn_pass(hn_op0, hn_nx, true);
+      WaveSync::sync();
+      for (uint32_t e = (uint32_t)lane; e < hn_ncopy; e += 64) {
+        const uint32_t w = A.hncopy[hn_copy0 + e];
+        lds_add(ua + (w & 0xffffu), ua[w >> 16]);
+      }
+      WaveSync::sync();
+    }
     // ---- batch results -> registers (stored during the next iteration); the next batch's gathered values -> LDS:
     // the iteration's one wait for the gather, issued a stage and a half ago
 #pragma unroll
@@ -522,23 +595,24 @@ apply_planes3(const ApplyArgs<T> A, const TablesEO<T, n> tab) {
 }
 
 template <int n, typename T>
-static size_t p_lds_bytes() {
-  return (size_t)p_kgu(n) * 64 * sizeof(double) + (size_t)2 * (p_cells_per_wave(n) + 1) * p_cell_stride(n) * sizeof(T);
+static size_t p_lds_bytes(bool hn) {
+  return ((size_t)p_kgu(n) * 64 + (hn ? (size_t)p_priv_max(n) + n * n : 0)) * sizeof(double) +
+         (size_t)2 * (p_cells_per_wave(n) + 1) * p_cell_stride(n) * sizeof(T);
 }
 
 template <int n, typename T>
-static hipError_t p_run(const ApplyArgs<T> &a, const double *S, const double *Dt, uint32_t grid, hipStream_t st,
+static hipError_t p_run(const ApplyArgs<T> &a, const double *S, const double *Dt, bool hn, uint32_t grid, hipStream_t st,
                         bool configure_only, size_t *lds_out, int *occupancy) {
-  const size_t lds = p_lds_bytes<n, T>();
+  const size_t lds = p_lds_bytes<n, T>(hn);
   if (lds_out) *lds_out = lds;
   if (configure_only) {
-    hipError_t e = hipFuncSetAttribute((const void *)apply_planes3<n, T, false>,
-                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    if (e == hipSuccess)
-      e = hipFuncSetAttribute((const void *)apply_planes3<n, T, true>, hipFuncAttributeMaxDynamicSharedMemorySize,
-                              (int)lds);
+    const void *f0 = hn ? (const void *)apply_planes3<n, T, false, true> : (const void *)apply_planes3<n, T, false, false>;
+    const void *f1 = hn ? (const void *)apply_planes3<n, T, true, true> : (const void *)apply_planes3<n, T, true, false>;
+    hipError_t e = hipFuncSetAttribute(f0, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    if (e == hipSuccess) e = hipFuncSetAttribute(f1, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     if (e == hipSuccess && occupancy)
-      e = hipOccupancyMaxActiveBlocksPerMultiprocessor(occupancy, apply_planes3<n, T, false>, 64, lds);
+      e = hn ? hipOccupancyMaxActiveBlocksPerMultiprocessor(occupancy, apply_planes3<n, T, false, true>, 64, lds)
+             : hipOccupancyMaxActiveBlocksPerMultiprocessor(occupancy, apply_planes3<n, T, false, false>, 64, lds);
     return e;
   }
   // S[i*n+q] = phi_i(x_q), Dt[q*n+t] = l_t'(x_q): full n x n, symmetrised by mfgpu_create
@@ -555,27 +629,34 @@ static hipError_t p_run(const ApplyArgs<T> &a, const double *S, const double *Dt
   for (int q = 0; q < h; ++q)
     for (int t = 0; t < m; ++t)
       tab.Do[q * m + t] = (T)(t < h ? 0.5 * (Dt[q * n + t] + Dt[q * n + (p - t)]) : Dt[q * n + t]);
-  if (a.add)
-    hipLaunchKernelGGL((apply_planes3<n, T, true>), dim3(grid), dim3(64), lds, st, a, tab);
-  else
-    hipLaunchKernelGGL((apply_planes3<n, T, false>), dim3(grid), dim3(64), lds, st, a, tab);
+  if (hn) {
+    if (a.add)
+      hipLaunchKernelGGL((apply_planes3<n, T, true, true>), dim3(grid), dim3(64), lds, st, a, tab);
+    else
+      hipLaunchKernelGGL((apply_planes3<n, T, false, true>), dim3(grid), dim3(64), lds, st, a, tab);
+  } else {
+    if (a.add)
+      hipLaunchKernelGGL((apply_planes3<n, T, true, false>), dim3(grid), dim3(64), lds, st, a, tab);
+    else
+      hipLaunchKernelGGL((apply_planes3<n, T, false, false>), dim3(grid), dim3(64), lds, st, a, tab);
+  }
   return hipGetLastError();
 }
 
 template <typename T>
-hipError_t p_launch(int n, const ApplyArgs<T> &a, const double *S, const double *Dt, uint32_t grid, hipStream_t st,
-                    bool configure_only, size_t *lds_out, int *occupancy) {
+hipError_t p_launch(int n, const ApplyArgs<T> &a, const double *S, const double *Dt, bool hn, uint32_t grid,
+                    hipStream_t st, bool configure_only, size_t *lds_out, int *occupancy) {
   switch (n) {
-    case 3: return p_run<3, T>(a, S, Dt, grid, st, configure_only, lds_out, occupancy);
-    case 4: return p_run<4, T>(a, S, Dt, grid, st, configure_only, lds_out, occupancy);
-    case 5: return p_run<5, T>(a, S, Dt, grid, st, configure_only, lds_out, occupancy);
+    case 3: return p_run<3, T>(a, S, Dt, hn, grid, st, configure_only, lds_out, occupancy);
+    case 4: return p_run<4, T>(a, S, Dt, hn, grid, st, configure_only, lds_out, occupancy);
+    case 5: return p_run<5, T>(a, S, Dt, hn, grid, st, configure_only, lds_out, occupancy);
     default: return hipErrorInvalidValue;
   }
 }
 
-template hipError_t p_launch<double>(int, const ApplyArgs<double> &, const double *, const double *, uint32_t,
+template hipError_t p_launch<double>(int, const ApplyArgs<double> &, const double *, const double *, bool, uint32_t,
                                      hipStream_t, bool, size_t *, int *);
-template hipError_t p_launch<float>(int, const ApplyArgs<float> &, const double *, const double *, uint32_t,
+template hipError_t p_launch<float>(int, const ApplyArgs<float> &, const double *, const double *, bool, uint32_t,
                                     hipStream_t, bool, size_t *, int *);
 
 // coefficient in plan cell order [cell][q] -> per batch [row r = y + n z][NT tasks = cell_in_batch * n + x]

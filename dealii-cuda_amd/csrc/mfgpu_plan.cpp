@@ -90,6 +90,37 @@ static void default_batch_limits(const mfgpu_desc &d, uint32_t max_chunks, uint3
   if (max_cells < 1) max_cells = 1;
 }
 
+void hn_cell_lines(unsigned mask, int n, std::vector<HnLine> (&lines)[3], std::vector<uint16_t> &nodes) {
+  const int p = n - 1;
+  const unsigned TYPE[3] = {1u << 0, 1u << 1, 1u << 2}, FACE[3] = {1u << 3, 1u << 4, 1u << 5};
+  const unsigned EDGE[3] = {1u << 7, 1u << 8, 1u << 6};  // direction x: edge YZ, y: ZX, z: XY (hanging_nodes.cuh:38-50)
+  const int stride[3] = {1, n, n * n};
+  std::vector<uint8_t> on(n * n * n, 0);
+  for (int d = 0; d < 3; ++d) {
+    lines[d].clear();
+    const int d1 = (d + 1) % 3, d2 = (d + 2) % 3;
+    if (!(mask & (FACE[d1] | FACE[d2] | EDGE[d]))) continue;
+    const int i1 = (mask & TYPE[d1]) ? 0 : p, i2 = (mask & TYPE[d2]) ? 0 : p;
+    const bool typ = (mask & TYPE[d]) != 0;
+    for (int a = 0; a < n; ++a)
+      for (int b = 0; b < n; ++b) {
+        const bool flag = ((mask & FACE[d1]) && a == i1) || ((mask & FACE[d2]) && b == i2) ||
+                          ((mask & EDGE[d]) && a == i1 && b == i2);
+        if (!flag) continue;
+        HnLine L{};
+        for (int t = 0; t < n; ++t) {
+          const int node = (typ ? t : p - t) * stride[d] + a * stride[d1] + b * stride[d2];
+          L.node[t] = (uint16_t)node;
+          on[node] = 1;
+        }
+        lines[d].push_back(L);
+      }
+  }
+  nodes.clear();
+  for (int i = 0; i < n * n * n; ++i)
+    if (on[i]) nodes.push_back((uint16_t)i);
+}
+
 int build_plan(const mfgpu_desc &d, Plan &P, uint32_t max_chunks, const PlanLimits *limits) {
   if (d.dim != 2 && d.dim != 3) {
     set_error("dim must be 2 or 3");
@@ -141,6 +172,25 @@ int build_plan(const mfgpu_desc &d, Plan &P, uint32_t max_chunks, const PlanLimi
   const bool segregate = limits && limits->segregate_masked && (d.flags & MFGPU_HANGING_NODES) && d.constraint_mask;
   uint32_t Bmax1 = 0, NBmax1 = 0;
   if (segregate) default_batch_limits(d, max_chunks, Bmax1, NBmax1);
+  // masked cells in plane batches of their own (apply_planes3<HN>): the plane limits, plus the private entries of the
+  // cells' constrained nodes (counted per mask value)
+  const bool masked_planes = segregate && limits->masked_planes && limits->max_cells && limits->max_dofs;
+  std::vector<uint32_t> priv_of_mask;  // mask value (9 bits) -> private entries of such a cell
+  if (masked_planes) {
+    priv_of_mask.assign(512, 0u);
+    std::vector<HnLine> ln[3];
+    std::vector<uint16_t> nodes;
+    for (unsigned m = 1; m < 512; ++m) {
+      hn_cell_lines(m, P.n, ln, nodes);
+      priv_of_mask[m] = (uint32_t)nodes.size();
+    }
+    for (uint32_t c = 0; c < nc; ++c)
+      if (d.constraint_mask[c] >= 512) {
+        set_error("constraint_mask has bits beyond the nine of hanging_nodes.cuh:38-50");
+        return MFGPU_EINVAL;
+      }
+  }
+  auto priv_of = [&](uint32_t c) { return masked_planes ? priv_of_mask[d.constraint_mask[c]] : 0u; };
   uint32_t Bmax, NBmax;
   if (limits && limits->max_cells && limits->max_dofs) {
     // kernel-imposed limits; the caller's knobs may only tighten them
@@ -201,16 +251,17 @@ int build_plan(const mfgpu_desc &d, Plan &P, uint32_t max_chunks, const PlanLimi
     std::vector<uint32_t> &cells = batches.back();
     const bool cls = masked(seed);
     batch_masked.push_back(cls);
-    const bool bound_surface = bound_surface_any && !cls;
-    const uint32_t Bmax_b = cls ? Bmax1 : Bmax, NBmax_b = cls ? NBmax1 : NBmax;
+    const bool bound_surface = bound_surface_any && (!cls || masked_planes);
+    const uint32_t Bmax_b = cls && !masked_planes ? Bmax1 : Bmax, NBmax_b = cls && !masked_planes ? NBmax1 : NBmax;
     cand.clear();
-    uint32_t ndofs = 0, n_enclosed = 0;
+    uint32_t ndofs = 0, n_enclosed = 0, npriv = 0;
     size_t last_ok = 0;
     uint32_t next = seed;
     while (true) {
       // add `next`
       cell_batch[next] = b;
       cells.push_back(next);
+      npriv += priv_of(next);
       for (uint32_t i = 0; i < nd; ++i) {
         const uint32_t g = l2g[(uint64_t)next * nd + i];
         const bool first = dof_stamp[g] != b;
@@ -256,6 +307,7 @@ int build_plan(const mfgpu_desc &d, Plan &P, uint32_t max_chunks, const PlanLimi
       cand.resize(w);
       if (best == NONE) break;
       if (ndofs + (nd - best_gain) > NBmax_b) break;
+      if (cls && masked_planes && npriv + priv_of(best) > limits->private_max) break;
       next = best;
     }
     if (last_ok == 0) last_ok = 1;  // (a single cell over the bound is reported by the classification below)
@@ -311,7 +363,7 @@ int build_plan(const mfgpu_desc &d, Plan &P, uint32_t max_chunks, const PlanLimi
         for (uint32_t i = 0; i < nd; ++i) v.push_back(l2g[(uint64_t)c * nd + i]);
       std::sort(v.begin(), v.end());
       v.erase(std::unique(v.begin(), v.end()), v.end());
-      if (v.size() > (batch_masked[b] ? NBmax1 : NBmax) || v.size() > 8191u) {
+      if (v.size() > (batch_masked[b] && !masked_planes ? NBmax1 : NBmax) || v.size() > 8191u) {
         // (the greedy estimate nd - gain under-counts a cell that lists one dof twice; the kernels hold a batch's
         // dofs in a fixed number of register / LDS slots and byte offsets of batch-local ids in 16 bits)
         set_error("internal: batch exceeds the kernel's dof slots (degenerate loc2glob?)");
@@ -323,7 +375,7 @@ int build_plan(const mfgpu_desc &d, Plan &P, uint32_t max_chunks, const PlanLimi
     for (uint32_t g = 0; g < N; ++g) shared_flag[g] = ntouch[g] >= 2;
     if (interior_max)  // constrained dofs a single PLANE batch touches are demoted (the pencil kernel writes its own)
       for (uint32_t b = 0; b < nb; ++b)
-        if (!batch_masked[b])
+        if (!batch_masked[b] || masked_planes)
           for (uint32_t g : bd[b])
             if (ntouch[g] == 1 && constrained[g]) shared_flag[g] = 1;
     nint.assign(nb, 0);
@@ -333,7 +385,7 @@ int build_plan(const mfgpu_desc &d, Plan &P, uint32_t max_chunks, const PlanLimi
       std::stable_partition(v.begin(), v.end(), [&](uint32_t g) { return !shared_flag[g]; });
       uint32_t k = 0;
       while (k < v.size() && !shared_flag[v[k]]) ++k;
-      if (interior_max && !batch_masked[b]) {
+      if (interior_max && (!batch_masked[b] || masked_planes)) {
         uint32_t keep = std::min(k, interior_max);
         if (keep == v.size() && keep > 0) --keep;
         for (uint32_t t = keep; t < k; ++t) shared_flag[v[t]] = 1;
@@ -353,7 +405,7 @@ int build_plan(const mfgpu_desc &d, Plan &P, uint32_t max_chunks, const PlanLimi
       std::vector<uint32_t> second(batches[b].begin() + half, batches[b].end());
       batches[b].resize(half);
       batches.insert(batches.begin() + b + 1, std::move(second));
-      batch_masked.insert(batch_masked.begin() + b + 1, (uint8_t)0);
+      batch_masked.insert(batch_masked.begin() + b + 1, batch_masked[b]);
     }
   }
 
@@ -455,7 +507,8 @@ int build_plan(const mfgpu_desc &d, Plan &P, uint32_t max_chunks, const PlanLimi
     P.batch_nint.push_back(nint[b]);
     // (apply_planes3: every batch owns a fixed number of halo slots, so a slot index follows from the batch index)
     P.halo_off.push_back(P.halo_off.back() +
-                         (interior_max && !batch_masked[b] ? limits->halo_stride : (uint32_t)(v.size() - nint[b])));
+                         (interior_max && (!batch_masked[b] || masked_planes) ? limits->halo_stride
+                                                                              : (uint32_t)(v.size() - nint[b])));
     for (uint32_t g : v) {
       uint8_t f = 0;
       if (constrained[g]) f |= kFlagConstrained;
@@ -480,9 +533,12 @@ int build_plan(const mfgpu_desc &d, Plan &P, uint32_t max_chunks, const PlanLimi
     P.max_batch_dofs = std::max<uint32_t>(P.max_batch_dofs, (uint32_t)v.size());
     P.max_batch_cells = std::max<uint32_t>(P.max_batch_cells, (uint32_t)batches[b].size());
   }
-  P.n_plane_batches = 0;
+  P.n_plane_batches = P.n_plain_plane_batches = 0;
   if (interior_max)
-    for (uint32_t k = 0; k < nb; ++k) P.n_plane_batches += batch_masked[order[k]] ? 0u : 1u;
+    for (uint32_t k = 0; k < nb; ++k) {
+      P.n_plain_plane_batches += batch_masked[order[k]] ? 0u : 1u;
+      P.n_plane_batches += (batch_masked[order[k]] && !masked_planes) ? 0u : 1u;
+    }
   P.orphans.clear();
   for (uint32_t g = 0; g < N; ++g)
     if (!touched[g]) P.orphans.push_back(g | (constrained[g] ? 0x80000000u : 0u));
@@ -557,6 +613,9 @@ int choose_kernel_and_plan(const mfgpu_desc &d, KernelChoice &kc, Plan &plan) {
     lim.halo_stride = (uint32_t)p_hs(d.degree + 1) * 64u;
     lim.shared_max = lim.halo_stride - 1u;  // the list's last slot stays padding (idle tasks)
     lim.segregate_masked = hn;
+    // cells with a hanging-node mask run in the plane kernel too (apply_planes3<HN>), in batches of their own
+    lim.masked_planes = hn;
+    lim.private_max = (uint32_t)p_priv_max(d.degree + 1);
   }
   // apply_batches_x unrolls 4 chunks at p=3 (64-cell batches = 13^3 dofs like p=4); everything else 3
   int rc = build_plan(d, plan, (kc.pencils_x && d.degree == 3) ? 4u : 3u, kc.planes ? &lim : nullptr);

@@ -304,14 +304,14 @@ def test_adaptive_mesh_with_hanging_nodes(dim, p, nref, colored):
 @pytest.mark.parametrize("p,nref", [(4, 4), (2, 4), (3, 5)])
 @pytest.mark.parametrize("xk", [True, False])
 def test_adaptive_mesh_both_cell_loop_kernels(p, nref, xk):
-    """3D two-pass default on meshes with hanging nodes: apply_batches_x (at p = 4 for the batches of masked cells
-    only: the cells without a mask run in apply_planes3); mfgpu_desc.kernel = PENCILS selects apply_batches (which
-    also serves 2D and the coloured mode): same operator on an adaptive mesh."""
+    """3D two-pass default on meshes with hanging nodes: apply_planes3 at p = 4 (cells with a mask in batches of their
+    own, apply_planes3<HN>), apply_batches_x otherwise; mfgpu_desc.kernel = PENCILS selects apply_batches (which also
+    serves 2D and the coloured mode), PENCILS_X the pencil kernel at p = 4 too: same operator on an adaptive mesh."""
     mesh = mf.Mesh.adaptive(3, p, nref)
     od = oracle_desc_from_mesh(mesh, dtype=np.float64)
     mesh.desc.kernel = mf.KERNEL_AUTO if xk else mf.KERNEL_PENCILS
     op = mf.Operator(mesh.desc, mesh)
-    assert op.kernel_name() == (("apply_planes3+apply_batches_x" if p == 4 else "apply_batches_x") if xk else "apply_batches")
+    assert op.kernel_name() == (("apply_planes3" if p == 4 else "apply_batches_x") if xk else "apply_batches")
     rng = np.random.default_rng(5)
     x, y0 = rng.standard_normal(mesh.n_dofs), rng.standard_normal(mesh.n_dofs)
     assert rel(gpu_vmult(op, x), o.vmult(od, x)) <= 1e-12
@@ -329,7 +329,8 @@ def test_adaptive_mesh_multi_chunk_batches(p, nref, kern):
     mesh.desc.kernel = kern
     mesh.desc.max_cells_per_batch = 64
     op = mf.Operator(mesh.desc, mesh)
-    assert op.plan_stats()["max_batch_cells"] > 256 // (p + 1) ** 2
+    if not (kern == mf.KERNEL_AUTO and p == 4):  # (the plane kernel's batches are one wave: 64 / n cells)
+        assert op.plan_stats()["max_batch_cells"] > 256 // (p + 1) ** 2
     rng = np.random.default_rng(p + nref)
     x, y0 = rng.standard_normal(mesh.n_dofs), rng.standard_normal(mesh.n_dofs)
     assert rel(gpu_vmult(op, x), o.vmult(od, x)) <= 1e-12

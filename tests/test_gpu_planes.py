@@ -145,3 +145,52 @@ def test_renumbered_mesh_gives_the_same_operator(make, kern):
     assert rel(y1[ni], y0) <= 1e-12
     z = np.random.default_rng(4).standard_normal(mesh.n_dofs)
     assert rel(gpu_vmult(op, x1, y0=z), o.vmult_add(od1, z, x1)) <= 1e-12
+
+
+def _all_masks3():
+    out = [t | (xyz << 3) for xyz in range(1, 8) for t in range(8)]
+    for e in (1 << 6, 1 << 7, 1 << 8, (1 << 6) | (1 << 5), (1 << 7) | (1 << 3), (1 << 8) | (1 << 4)):
+        out += [e | t for t in range(8)]
+    return out
+
+
+@pytest.mark.parametrize("p,n,wgs,nt", [(4, 5, 0, mf.F64), (4, 6, 2, mf.F64), (4, 5, 3, mf.F32), (3, 5, 0, mf.F64), (3, 6, 2, mf.F64),
+                                        (2, 6, 0, mf.F64), (2, 7, 3, mf.F64)])
+def test_planes_hanging_node_batches_synthetic_masks(p, n, wgs, nt):
+    """apply_planes3<HN>: every mask of the reference's known-answer test (type x face bits, edge masks) on cells of a
+    conforming mesh -- private entries, interpolation passes x, y, z before the cell stages and the transposed passes
+    after them -- for every degree the plane kernel serves, few workgroups (several batches per workgroup) included;
+    vmult and vmult_add against the oracle's emulation of resolve_hanging_nodes (hanging_nodes.cuh:617-778)"""
+    od = o.uniform_mesh_desc(3, p, n)
+    masks = _all_masks3()
+    rng = np.random.default_rng(7 * p + n)
+    cm = np.zeros(od.n_cells, dtype=np.uint32)
+    pick = rng.permutation(od.n_cells)[:od.n_cells * 3 // 4]
+    cm[pick] = np.array(masks, dtype=np.uint32)[np.arange(len(pick)) % len(masks)]
+    od.constraint_mask = cm
+    x, y0 = rng.standard_normal(od.n_dofs), rng.standard_normal(od.n_dofs)
+    xt, y0t = (v.astype(mf.np_dtype(nt)).astype(np.float64) for v in (x, y0))
+    desc, keep = desc_from_oracle(od, number_type=nt, kernel=mf.KERNEL_PLANES, max_workgroups=wgs)
+    op = mf.Operator(desc, keep)
+    assert op.kernel_name() == "apply_planes3"
+    assert rel(gpu_vmult(op, x, nt), o.vmult(od, xt)) <= TOL[nt]
+    assert rel(gpu_vmult(op, x, nt, y0=y0), o.vmult_add(od, y0t, xt)) <= TOL[nt]
+
+
+@pytest.mark.parametrize("p,nref", [(4, 4), (4, 5), (3, 4), (2, 5)])
+def test_planes_adaptive_mesh_and_inverse_diagonal(p, nref):
+    """bmop -DADAPTIVE_GRID mesh entirely in the plane kernel (cells with a mask in batches of their own); the inverse
+    diagonal runs on the same plan"""
+    mesh = mf.Mesh.adaptive(3, p, nref)
+    od = oracle_desc_from_mesh(mesh)
+    mesh.desc.kernel = mf.KERNEL_PLANES
+    op = mf.Operator(mesh.desc, mesh)
+    assert op.kernel_name() == "apply_planes3"
+    rng = np.random.default_rng(p + nref)
+    x, y0 = rng.standard_normal(mesh.n_dofs), rng.standard_normal(mesh.n_dofs)
+    assert rel(gpu_vmult(op, x), o.vmult(od, x)) <= 1e-12
+    assert rel(gpu_vmult(op, x, y0=y0), o.vmult_add(od, y0, x)) <= 1e-12
+    d = mf.DeviceVector(mesh.n_dofs)
+    op.compute_inverse_diagonal(d)
+    mf.synchronize()
+    assert rel(d.to_host(), o.compute_inverse_diagonal(od)) <= 1e-12
