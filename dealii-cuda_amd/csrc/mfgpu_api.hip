@@ -35,7 +35,7 @@ struct mfgpu_handle {
   uint16_t *d_perm = nullptr;  // apply_batches_x: bank-conflict-free lane -> pencil maps of the y- and z-stage
   // apply_planes3: fixed-size per-batch records (see ApplyArgs)
   uint32_t *d_bdofsp = nullptr, *d_idxp = nullptr;
-  uint32_t *d_hnhdr = nullptr, *d_hncopy = nullptr, *d_hnops = nullptr;  // apply_planes3<HN>: per-batch line operations
+  uint32_t *d_hnrec = nullptr;  // apply_planes3<HN>: per-batch records of the hanging-node line operations
   void *d_coefp = nullptr;
   void *d_coef = nullptr;
   uint32_t *d_cmask = nullptr, *d_orphans = nullptr;
@@ -238,7 +238,8 @@ int create_arrays(mfgpu_handle *h, const mfgpu_desc &d) {
     // touches) get PRIVATE positions behind the dof list; the cell's index runs point there.  Per batch: a copy list
     // (private position <- position of the node's dof in the list) and per direction the line operations, each the n
     // private positions of a line in the order the plain weight matrix applies to (hn_cell_lines).
-    std::vector<uint32_t> hnhdr, hncopy, hnops;
+    const int HROWS = p_hn_rows(n), CR = p_priv_max(n) / 64;
+    std::vector<uint32_t> hnrec((size_t)(nbat - P.n_plain_plane_batches) * HROWS * 64, 0u);
     std::vector<HnLine> lines[3];
     std::vector<uint16_t> pnodes;
     std::vector<uint32_t> priv_pos((size_t)P.nd);
@@ -260,27 +261,26 @@ int create_arrays(mfgpu_handle *h, const mfgpu_desc &d) {
       }
       const bool hnb = b >= npl_plain;
       uint32_t next_priv = (uint32_t)NB;
-      uint32_t hdr[8] = {(uint32_t)hncopy.size(), 0u, (uint32_t)(hnops.size() / 4), 0u, 0u, 0u, 0u, 0u};
-      std::vector<uint32_t> ops_d[3];
+      std::vector<uint32_t> copies, ops_d[3];
       for (uint32_t c = 0; c < nc; ++c) {
         const unsigned mask = hnb ? d.constraint_mask[P.cell_order[c0 + c]] : 0u;
         std::fill(priv_pos.begin(), priv_pos.end(), 0xffffffffu);
         if (mask) {
           hn_cell_lines(mask, n, lines, pnodes);
           for (uint16_t node : pnodes) {
-            if (next_priv >= (uint32_t)NB + (uint32_t)p_priv_max(n)) {
+            if (next_priv >= (uint32_t)NB + (uint32_t)p_priv_max(n)) {  // (the planner budgets them)
               set_error("internal: batch exceeds the plane kernel's private hanging-node entries");
               return MFGPU_EINVAL;
             }
             priv_pos[node] = next_priv;
-            hncopy.push_back((next_priv << 16) | slot_of[P.lmap[(size_t)(c0 + c) * P.nd + node]]);
+            copies.push_back((next_priv << 16) | slot_of[P.lmap[(size_t)(c0 + c) * P.nd + node]]);
             ++next_priv;
           }
           for (int dir = 0; dir < 3; ++dir)
             for (const HnLine &L : lines[dir]) {
-              uint32_t w[4] = {0u, 0u, 0u, 0u};
+              uint32_t w[3] = {0u, 0u, 0u};
               for (int t = 0; t < n; ++t) w[t >> 1] |= priv_pos[L.node[t]] << (16 * (t & 1));
-              ops_d[dir].insert(ops_d[dir].end(), w, w + 4);
+              ops_d[dir].insert(ops_d[dir].end(), w, w + 3);
             }
         }
         for (int k = 0; k < n; ++k)
@@ -293,21 +293,28 @@ int create_arrays(mfgpu_handle *h, const mfgpu_desc &d) {
           }
       }
       if (hnb) {
-        hdr[1] = (uint32_t)hncopy.size() - hdr[0];
+        uint32_t *rec = hnrec.data() + (size_t)(b - npl_plain) * HROWS * 64;
+        for (size_t e = 0; e < copies.size(); ++e) rec[e] = copies[e];  // rows 0 .. CR-1, entry e at [e / 64][e % 64]
         for (int dir = 0; dir < 3; ++dir) {
-          hdr[3 + dir] = (uint32_t)(ops_d[dir].size() / 4);
-          hnops.insert(hnops.end(), ops_d[dir].begin(), ops_d[dir].end());
+          const size_t nops = ops_d[dir].size() / 3;
+          if (nops > (size_t)kHnOpRounds * 64) {
+            set_error("internal: more hanging-node lines in a batch than the plane kernel's record holds");
+            return MFGPU_EINVAL;
+          }
+          for (size_t e = 0; e < nops; ++e)
+            for (int w = 0; w < 3; ++w)
+              rec[(size_t)(CR + (dir * kHnOpRounds + (int)(e / 64)) * 3 + w) * 64 + e % 64] = ops_d[dir][e * 3 + w];
         }
-        hnhdr.insert(hnhdr.end(), hdr, hdr + 8);
+        const uint32_t h0 = (uint32_t)copies.size() | ((uint32_t)(ops_d[0].size() / 3) << 16);
+        const uint32_t h1 = (uint32_t)(ops_d[1].size() / 3) | ((uint32_t)(ops_d[2].size() / 3) << 16);
+        for (int l = 0; l < 64; ++l) {
+          rec[(size_t)(HROWS - 2) * 64 + l] = h0;
+          rec[(size_t)(HROWS - 1) * 64 + l] = h1;
+        }
       }
     }
-    if (!hnhdr.empty()) {
-      hncopy.push_back(0u);  // (never empty)
-      hnops.resize(hnops.size() + 4, 0u);
-      if ((rc = dev_upload(&h->d_hnhdr, hnhdr.data(), hnhdr.size() * 4, acct))) return rc;
-      if ((rc = dev_upload(&h->d_hncopy, hncopy.data(), hncopy.size() * 4, acct))) return rc;
-      if ((rc = dev_upload(&h->d_hnops, hnops.data(), hnops.size() * 4, acct))) return rc;
-    }
+    if (!hnrec.empty())
+      if ((rc = dev_upload(&h->d_hnrec, hnrec.data(), hnrec.size() * 4, acct))) return rc;
     if ((rc = dev_upload(&h->d_bdofsp, bd.data(), bd.size() * 4, acct))) return rc;
     if ((rc = dev_upload(&h->d_idxp, ix.data(), ix.size() * 4, acct))) return rc;
   }
@@ -594,9 +601,7 @@ int vmult_main(mfgpu_handle *h, void *dst, const void *src, hipStream_t st, int 
   a.perm = h->d_perm;
   a.bdofsp = h->d_bdofsp;
   a.idxp = h->d_idxp;
-  a.hnhdr = h->d_hnhdr;
-  a.hncopy = h->d_hncopy;
-  a.hnops = reinterpret_cast<const uint4 *>(h->d_hnops);
+  a.hnrec = h->d_hnrec;
   a.hn_batch0 = P.n_plain_plane_batches;
   a.coefp = (const T *)h->d_coefp;
   a.coef = (const T *)h->d_coef;
@@ -836,9 +841,7 @@ void mfgpu_destroy(mfgpu_handle *h) {
   hipFree(h->d_perm);
   hipFree(h->d_bdofsp);
   hipFree(h->d_idxp);
-  hipFree(h->d_hnhdr);
-  hipFree(h->d_hncopy);
-  hipFree(h->d_hnops);
+  hipFree(h->d_hnrec);
   hipFree(h->d_coefp);
   hipFree(h->d_constrained);
   hipFree(h->d_tab2);

@@ -64,6 +64,12 @@ constexpr uint32_t kCarryBit = 1u << 30;  // dof-list entry of apply_planes3: th
 // passes of resolve_hanging_nodes (hanging_nodes.cuh:617-696) run line by line before the cell stages, and their
 // transposes after them (mfgpu_plan.cpp hn_cell_lines, mfgpu_kernels_p.hip)
 constexpr int p_priv_max(int n) { return n == 5 ? 384 : n == 4 ? 256 : 192; }
+// ... and its fixed-size per-batch record of 32-bit words, stored [row][lane] (a wave reads a row with one coalesced
+// load, one batch ahead): p_priv_max / 64 rows of copies (private position << 16 | dof-list position), then per
+// direction (x, y, z) kHnOpRounds rounds of line operations, 3 rows each (the n <= 5 private positions of lane's line,
+// 16 bit each), then 2 rows with the counts (copies | x lines << 16; y lines | z lines << 16) in every lane
+constexpr int kHnOpRounds = 2;
+constexpr int p_hn_rows(int n) { return p_priv_max(n) / 64 + 3 * kHnOpRounds * 3 + 2; }
 
 constexpr uint8_t kFlagConstrained = 1;  // batch dof is a constrained row (identity)
 constexpr uint8_t kFlagAdd = 2;          // batch is NOT the first toucher: dst += (else dst =)

@@ -21,10 +21,8 @@ struct ApplyArgs {
   const uint32_t *bdofsp;  // [p_kgu(n) * 64] dof list: p_ji(n) slots of interior dofs, p_hs(n) slots of pass-2 dofs
   const uint32_t *idxp;    // [(n*n+1)/2 words][NT tasks] packed 16-bit byte offsets into the batch array
   const T *coefp;          // [n*n rows][NT tasks] folded coefficient
-  // apply_planes3<HN> (batches hn_batch0 ..): per batch {copy offset, copies, first line op, ops x, ops y, ops z, -, -},
-  // copies (private position << 16 | dof-list position), line ops (n private positions, 16 bit each, in a uint4)
-  const uint32_t *hnhdr, *hncopy;
-  const uint4 *hnops;
+  // apply_planes3<HN> (batches hn_batch0 ..): fixed-size records of p_hn_rows(n) x 64 words (mfgpu_internal.h)
+  const uint32_t *hnrec;
   uint32_t hn_batch0;
   const T *coef;          // folded a*J0^2*JxW (apply_batches_g: the 6 entries of a*JxW*J*J^T), plan cell order
   const uint32_t *cmask;  // plan cell order, or nullptr

@@ -256,11 +256,19 @@ apply_planes3(const ApplyArgs<T> A, const TablesEO<T, n> tab) {
   uint32_t b1 = next_of(b), b2 = next_of(b1);
   uint32_t Gp[KGU], Gc[KGU], Gn[KGU], Gnn[KGU];  // dof lists: previous (its scatter is deferred), current, two ahead
   uint32_t IXc[NIW], IXn[NIW];
+  constexpr int CR = PRIV / 64, HROWS = HN ? p_hn_rows(n) : 1;
+  uint32_t Hc[HROWS], Hn[HROWS];  // HN: this batch's and the next batch's hanging-node record
+  auto load_hn = [&](uint32_t bb, uint32_t (&H)[HROWS]) {
+    const uint32_t *p = A.hnrec + (size_t)(bb - A.hn_batch0) * (HROWS * 64) + lane;
+#pragma unroll
+    for (int w = 0; w < HROWS; ++w) H[w] = nt_load(p + w * 64);
+  };
   T Cc[n2];
   T SVn[KGU], R[KGU], old[KGU];
   load_dofs(b, Gc);
   load_dofs(b1, Gn);
   load_ix(b, IXc);
+  if (HN) load_hn(b, Hc);
   // the idle lanes add into the batch array's last slot, which is never a dof
   constexpr uint32_t kDummyIx = 8u * (uint32_t)(KGU * 64 - 1) * 0x10001u;
 #pragma unroll
@@ -290,19 +298,26 @@ apply_planes3(const ApplyArgs<T> A, const TablesEO<T, n> tab) {
 
   while (true) {
     const bool has_next = b1 != b;
-    // ---- hanging-node batches: private copies of the constrained nodes, then the interpolation passes x, y, z
-    uint32_t hn_copy0 = 0, hn_ncopy = 0, hn_op0 = 0, hn_nx = 0, hn_ny = 0, hn_nz = 0;
-    auto hn_pass = [&](uint32_t first, uint32_t count, bool transposed) {
-      for (uint32_t e0 = 0; e0 < count; e0 += 64) {  // (uniform trip count)
-        const uint32_t e = e0 + (uint32_t)lane;
-        const bool on = e < count;
-        const uint4 w = A.hnops[first + (on ? e : 0u)];
-        const uint32_t ww[4] = {w.x, w.y, w.z, w.w};
+    // ---- hanging-node batches: private copies of the constrained nodes, then the interpolation passes x, y, z.
+    // The batch's record (copies, line operations, counts) was requested one batch ahead with the other coalesced
+    // loads; lanes beyond a count work on nothing.
+    const uint32_t hn_ncopy = HN ? (uint32_t)__builtin_amdgcn_readfirstlane(Hc[HROWS - 2] & 0xffffu) : 0u;
+    auto hn_count = [&](int dir) -> uint32_t {
+      const uint32_t w = dir == 0 ? Hc[HROWS - 2] >> 16 : dir == 1 ? Hc[HROWS - 1] & 0xffffu : Hc[HROWS - 1] >> 16;
+      return (uint32_t)__builtin_amdgcn_readfirstlane(w);
+    };
+    auto hn_pass = [&](int dir, bool transposed) {
+      const uint32_t count = hn_count(dir);
+#pragma unroll
+      for (int r = 0; r < kHnOpRounds; ++r) {
+        if ((uint32_t)(r * 64) >= count) break;  // uniform
+        const bool on = (uint32_t)(r * 64 + lane) < count;
+        const uint32_t *ww = &Hc[CR + (dir * kHnOpRounds + r) * 3];
         double v[n], o[n];
         uint32_t pos[n];
 #pragma unroll
         for (int t = 0; t < n; ++t) {
-          pos[t] = (ww[t >> 1] >> (16 * (t & 1))) & 0xffffu;
+          pos[t] = on ? (ww[t >> 1] >> (16 * (t & 1))) & 0xffffu : (uint32_t)(KGU * 64 + PRIV - 1);
           v[t] = ua[pos[t]];
         }
 #pragma unroll
@@ -319,23 +334,17 @@ apply_planes3(const ApplyArgs<T> A, const TablesEO<T, n> tab) {
       }
     };
     if (HN) {
-      const uint32_t *hd = A.hnhdr + (size_t)(b - A.hn_batch0) * 8;
-      hn_copy0 = __builtin_amdgcn_readfirstlane(hd[0]);
-      hn_ncopy = __builtin_amdgcn_readfirstlane(hd[1]);
-      hn_op0 = __builtin_amdgcn_readfirstlane(hd[2]);
-      hn_nx = __builtin_amdgcn_readfirstlane(hd[3]);
-      hn_ny = __builtin_amdgcn_readfirstlane(hd[4]);
-      hn_nz = __builtin_amdgcn_readfirstlane(hd[5]);
-      for (uint32_t e = (uint32_t)lane; e < hn_ncopy; e += 64) {
-        const uint32_t w = A.hncopy[hn_copy0 + e];
-        ua[w >> 16] = ua[w & 0xffffu];
+#pragma unroll
+      for (int r = 0; r < CR; ++r) {
+        if ((uint32_t)(r * 64) >= hn_ncopy) break;  // uniform
+        if ((uint32_t)(r * 64 + lane) < hn_ncopy) ua[Hc[r] >> 16] = ua[Hc[r] & 0xffffu];
       }
       WaveSync::sync();
-      hn_pass(hn_op0, hn_nx, false);
+      hn_pass(0, false);
       WaveSync::sync();
-      hn_pass(hn_op0 + hn_nx, hn_ny, false);
+      hn_pass(1, false);
       WaveSync::sync();
-      hn_pass(hn_op0 + hn_nx + hn_ny, hn_nz, false);
+      hn_pass(2, false);
       WaveSync::sync();
     }
     STAMP(0);
@@ -346,6 +355,7 @@ apply_planes3(const ApplyArgs<T> A, const TablesEO<T, n> tab) {
     // ---- coalesced loads of the coming batches: dof list two ahead, index runs one ahead
     load_dofs(b2, Gnn);
     load_ix(b1, IXn);
+    if (HN) load_hn(b1, Hn);
     if (ADD) {
 #pragma unroll
       for (int j = 0; j < JI; ++j) old[j] = *dst_at(Gp[j]);
@@ -547,15 +557,16 @@ apply_planes3(const ApplyArgs<T> A, const TablesEO<T, n> tab) {
 
     if (HN) {
       // the transposed passes in reverse order, then the private entries' sums go to their dofs' entries
-      hn_pass(hn_op0 + hn_nx + hn_ny, hn_nz, true);
+      hn_pass(2, true);
       WaveSync::sync();
-      hn_pass(hn_op0 + hn_nx, hn_ny, true);
+      hn_pass(1, true);
       WaveSync::sync();
-      hn_pass(hn_op0, hn_nx, true);
+      hn_pass(0, true);
       WaveSync::sync();
-      for (uint32_t e = (uint32_t)lane; e < hn_ncopy; e += 64) {
-        const uint32_t w = A.hncopy[hn_copy0 + e];
-        lds_add(ua + (w & 0xffffu), ua[w >> 16]);
+#pragma unroll
+      for (int r = 0; r < CR; ++r) {
+        if ((uint32_t)(r * 64) >= hn_ncopy) break;  // uniform
+        if ((uint32_t)(r * 64 + lane) < hn_ncopy) lds_add(ua + (Hc[r] & 0xffffu), ua[Hc[r] >> 16]);
       }
       WaveSync::sync();
     }
@@ -584,6 +595,10 @@ apply_planes3(const ApplyArgs<T> A, const TablesEO<T, n> tab) {
     }
 #pragma unroll
     for (int w = 0; w < NIW; ++w) IXc[w] = lane_on ? IXn[w] : kDummyIx;
+    if (HN) {
+#pragma unroll
+      for (int w = 0; w < HROWS; ++w) Hc[w] = Hn[w];
+    }
   }
   // the last batch's results
   if (ADD) {
