@@ -603,7 +603,9 @@ int choose_kernel_and_plan(const mfgpu_desc &d, KernelChoice &kc, Plan &plan) {
   }
   kc.general = general;
   // by default the plane kernel serves p = 4 only: at p = 2, 3 the pencil kernel measures faster
-  kc.planes = pk_ok && (d.kernel == MFGPU_KERNEL_PLANES || (d.kernel == MFGPU_KERNEL_AUTO && d.degree == 4));
+  // (on meshes with hanging nodes also p = 3: 0.174 instead of 0.256 ms on the bmop ADAPTIVE_GRID mesh, n_ref = 6)
+  kc.planes = pk_ok && (d.kernel == MFGPU_KERNEL_PLANES ||
+                        (d.kernel == MFGPU_KERNEL_AUTO && (d.degree == 4 || (hn && d.degree == 3))));
   kc.pencils_x = xk_ok && !kc.planes && d.kernel != MFGPU_KERNEL_PENCILS;
   PlanLimits lim;
   if (kc.planes) {

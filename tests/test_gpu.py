@@ -311,7 +311,7 @@ def test_adaptive_mesh_both_cell_loop_kernels(p, nref, xk):
     od = oracle_desc_from_mesh(mesh, dtype=np.float64)
     mesh.desc.kernel = mf.KERNEL_AUTO if xk else mf.KERNEL_PENCILS
     op = mf.Operator(mesh.desc, mesh)
-    assert op.kernel_name() == (("apply_planes3" if p == 4 else "apply_batches_x") if xk else "apply_batches")
+    assert op.kernel_name() == (("apply_planes3" if p >= 3 else "apply_batches_x") if xk else "apply_batches")
     rng = np.random.default_rng(5)
     x, y0 = rng.standard_normal(mesh.n_dofs), rng.standard_normal(mesh.n_dofs)
     assert rel(gpu_vmult(op, x), o.vmult(od, x)) <= 1e-12
@@ -329,7 +329,7 @@ def test_adaptive_mesh_multi_chunk_batches(p, nref, kern):
     mesh.desc.kernel = kern
     mesh.desc.max_cells_per_batch = 64
     op = mf.Operator(mesh.desc, mesh)
-    if not (kern == mf.KERNEL_AUTO and p == 4):  # (the plane kernel's batches are one wave: 64 / n cells)
+    if not (kern == mf.KERNEL_AUTO and p >= 3):  # (the plane kernel's batches are one wave: 64 / n cells)
         assert op.plan_stats()["max_batch_cells"] > 256 // (p + 1) ** 2
     rng = np.random.default_rng(p + nref)
     x, y0 = rng.standard_normal(mesh.n_dofs), rng.standard_normal(mesh.n_dofs)
