@@ -21,12 +21,11 @@ inline int ipow(int a, int e) {
 // ---- apply_planes3 (mfgpu_kernels_p.hip): a wave owns 64 / n cells (n lanes per cell).  A batch's dof list has a
 // FIXED structure of 64-lane slots: p_ji(n) slots of interior dofs (stored to dst by the cell loop) followed by
 // p_hs(n) slots of pass-2 dofs (partial sums to the halo buffer), sized for the most compact batch of 64 / n cells
-// (3x2x2 cells at p = 4: 539 interior, 514 surface dofs; with the faces carried between x-neighbours 49 + 49 of the
-// surface dofs sit in the interior slots).  Cells of the LDS transpose arrays are p_cell_stride(n)
+// (3x2x2 cells at p = 4: 539 interior, 514 surface dofs).  Cells of the LDS transpose arrays are p_cell_stride(n)
 // values apart (stride = n mod 32: the 16-lane store groups and 32-lane load groups of the yz-plane stage hit
 // distinct banks).
 constexpr int p_cells_per_wave(int n) { return 64 / n; }
-constexpr int p_ji(int n) { return n == 3 ? 2 : n == 4 ? 5 : 10; }
+constexpr int p_ji(int n) { return n == 3 ? 2 : n == 4 ? 5 : 9; }
 constexpr int p_hs(int n) { return n == 3 ? 3 : n == 4 ? 6 : 9; }
 constexpr int p_kgu(int n) { return p_ji(n) + p_hs(n); }
 constexpr int p_cell_stride(int n) {
@@ -34,30 +33,6 @@ constexpr int p_cell_stride(int n) {
   while ((s & 31) != (n & 31)) ++s;
   return s;
 }
-
-// A workgroup of apply_planes3 processes a CONTIGUOUS range of batches (XCD-aware: workgroup i runs on XCD i % 8 and
-// the XCD's workgroups share one contiguous range of the launch): batches that follow each other in x are processed
-// by the same wave, which CARRIES the partial sums of their common face from one iteration to the next in registers
-// (mfgpu_api.hip, build of the plane records; bit 30 of a dof-list entry).  The host builds the records with this very
-// function, so kernel and records always agree on the ranges.
-#ifdef __HIPCC__
-#define MFGPU_HD __host__ __device__
-#else
-#define MFGPU_HD
-#endif
-MFGPU_HD inline void p_wg_range(uint32_t nbt, uint32_t G, uint32_t wg, uint32_t &lo, uint32_t &hi) {
-  if (G >= 8) {
-    const uint32_t xcd = wg & 7u, slot = wg >> 3, q = G >> 3, rem = G & 7u;
-    const uint32_t wlo = xcd * q + (xcd < rem ? xcd : rem), w = q + (xcd < rem ? 1u : 0u);
-    const uint32_t xlo = (uint32_t)((uint64_t)nbt * wlo / G), xhi = (uint32_t)((uint64_t)nbt * (wlo + w) / G);
-    lo = xlo + (uint32_t)((uint64_t)(xhi - xlo) * slot / w);
-    hi = xlo + (uint32_t)((uint64_t)(xhi - xlo) * (slot + 1) / w);
-  } else {
-    lo = (uint32_t)((uint64_t)nbt * wg / G);
-    hi = (uint32_t)((uint64_t)nbt * (wg + 1) / G);
-  }
-}
-constexpr uint32_t kCarryBit = 1u << 30;  // dof-list entry of apply_planes3: the partial sum is carried to the next batch
 
 // apply_planes3 on cells WITH a hanging-node mask: the constrained nodes of a cell get PRIVATE entries behind the
 // batch's dof list (p_priv_max(n) of them per batch), a copy of the gathered values, on which the 1D interpolation
@@ -101,6 +76,9 @@ struct Plan {
   uint32_t max_batch_dofs = 0, max_batch_cells = 0;
   uint32_t n_plane_batches = 0;  // the first n_plane_batches batches run in apply_planes3, the rest in apply_batches_x
   uint32_t n_plain_plane_batches = 0;  // ... of which the first n_plain_plane_batches hold cells without a mask only
+  // apply_planes3 (build_plane_records): fixed-size per-batch records -- dof lists, index runs, and for the batches of
+  // masked cells the hanging-node records
+  std::vector<uint32_t> pr_dofs, pr_idx, pr_hn;
   uint64_t n_first = 0, n_add = 0;
 };
 
@@ -147,6 +125,7 @@ struct KernelChoice {
   bool planes = false, pencils_x = false, general = false;
 };
 int choose_kernel_and_plan(const mfgpu_desc &d, KernelChoice &kc, Plan &plan);
+int build_plane_records(Plan &plan, const uint32_t *constraint_mask);
 
 // Derive the kernel's 1D tables from the reference-layout tables T[dof*n+q]:
 //   S[i*n+q]  = shape_values (interpolation nodal -> quadrature points)

@@ -585,6 +585,106 @@ int build_plan(const mfgpu_desc &d, Plan &P, uint32_t max_chunks, const PlanLimi
   return 0;
 }
 
+// Fixed-size per-batch records of apply_planes3.  Dof list: p_ji slots of interior dofs, padded with a pass-2 dof
+// of the batch (the padding lanes store the zero their never-touched accumulator slot holds, or old + 0, to a dof
+// pass 2 rewrites), then p_hs slots of pass-2 dofs, padded with the last one.  Index runs: per task (cell c, plane
+// k) the n*n slot numbers of the xy-plane z = k as byte offsets (slot * 8) packed two per word, stored
+// [word][task] so that a wave reads consecutive words; the tasks of cells a ragged batch does not have point at
+// the list's last slot, which is padding in every batch the planner accepts.
+// (constraint_mask: the description's, caller's cell order; nullptr on conforming meshes)
+int build_plane_records(Plan &P, const uint32_t *constraint_mask) {
+  const int n = P.n, n2 = n * n, NT = p_cells_per_wave(n) * n, NIW = (n2 + 1) / 2;
+  const int JI = p_ji(n) * 64, NB = p_kgu(n) * 64;
+  const size_t nbat = P.n_plane_batches;
+  const uint32_t dummy = 8u * (uint32_t)(NB - 1);
+  std::vector<uint32_t> &bd = P.pr_dofs, &ix = P.pr_idx;
+  bd.assign((size_t)NB * nbat, 0u);
+  ix.assign((size_t)NIW * NT * nbat, dummy | (dummy << 16));
+  std::vector<uint32_t> slot_of;  // batch-local id (position in P.bdofs) -> slot
+  // batches of cells WITH a hanging-node mask (apply_planes3<HN>, the plan's batches n_plain_plane_batches ..): the
+  // constrained nodes of a cell (those on a line one of the interpolation passes of hanging_nodes.cuh:617-696
+  // touches) get PRIVATE positions behind the dof list; the cell's index runs point there.  Per batch: a copy list
+  // (private position <- position of the node's dof in the list) and per direction the line operations, each the n
+  // private positions of a line in the order the plain weight matrix applies to (hn_cell_lines).
+  const int HROWS = p_hn_rows(n), CR = p_priv_max(n) / 64;
+  std::vector<uint32_t> &hnrec = P.pr_hn;
+  hnrec.assign((size_t)(nbat - P.n_plain_plane_batches) * HROWS * 64, 0u);
+  std::vector<HnLine> lines[3];
+  std::vector<uint16_t> pnodes;
+  std::vector<uint32_t> priv_pos((size_t)P.nd);
+  const uint32_t npl_plain = P.n_plain_plane_batches;
+  for (size_t b = 0; b < nbat; ++b) {
+    const uint32_t c0 = P.batch_cell_off[b], nc = P.batch_cell_off[b + 1] - c0;
+    const uint32_t d0 = P.batch_dof_off[b], nbd = P.batch_dof_off[b + 1] - d0, ni = P.batch_nint[b];
+    if ((int)nc * n > NT || (int)ni > JI || (int)(nbd - ni) >= NB - JI || nbd == ni) {
+      set_error("internal: batch does not fit the plane kernel's dof-list slots");
+      return MFGPU_EINVAL;
+    }
+    slot_of.assign(nbd, 0u);
+    for (uint32_t t = 0; t < nbd; ++t) slot_of[t] = t < ni ? t : (uint32_t)JI + (t - ni);
+    for (int t = 0; t < NB; ++t) {
+      uint32_t src_t;
+      if (t < JI) src_t = (uint32_t)t < ni ? (uint32_t)t : ni;  // padding: the first pass-2 dof
+      else src_t = std::min<uint32_t>(ni + (uint32_t)(t - JI), nbd - 1);
+      bd[b * NB + t] = P.bdofs[d0 + src_t];
+    }
+    const bool hnb = b >= npl_plain;
+    uint32_t next_priv = (uint32_t)NB;
+    std::vector<uint32_t> copies, ops_d[3];
+    for (uint32_t c = 0; c < nc; ++c) {
+      const unsigned mask = hnb ? constraint_mask[P.cell_order[c0 + c]] : 0u;
+      std::fill(priv_pos.begin(), priv_pos.end(), 0xffffffffu);
+      if (mask) {
+        hn_cell_lines(mask, n, lines, pnodes);
+        for (uint16_t node : pnodes) {
+          if (next_priv >= (uint32_t)NB + (uint32_t)p_priv_max(n)) {  // (the planner budgets them)
+            set_error("internal: batch exceeds the plane kernel's private hanging-node entries");
+            return MFGPU_EINVAL;
+          }
+          priv_pos[node] = next_priv;
+          copies.push_back((next_priv << 16) | slot_of[P.lmap[(size_t)(c0 + c) * P.nd + node]]);
+          ++next_priv;
+        }
+        for (int dir = 0; dir < 3; ++dir)
+          for (const HnLine &L : lines[dir]) {
+            uint32_t w[3] = {0u, 0u, 0u};
+            for (int t = 0; t < n; ++t) w[t >> 1] |= priv_pos[L.node[t]] << (16 * (t & 1));
+            ops_d[dir].insert(ops_d[dir].end(), w, w + 3);
+          }
+      }
+      for (int k = 0; k < n; ++k)
+        for (int i = 0; i < n2; ++i) {
+          const int node = i + n2 * k;
+          const uint32_t pos = priv_pos[node] != 0xffffffffu ? priv_pos[node] : slot_of[P.lmap[(size_t)(c0 + c) * P.nd + node]];
+          const uint32_t off = 8u * pos;
+          uint32_t &w = ix[(b * NIW + i / 2) * NT + c * n + k];
+          w = (i & 1) ? ((w & 0xffffu) | (off << 16)) : ((w & 0xffff0000u) | off);
+        }
+    }
+    if (hnb) {
+      uint32_t *rec = hnrec.data() + (size_t)(b - npl_plain) * HROWS * 64;
+      for (size_t e = 0; e < copies.size(); ++e) rec[e] = copies[e];  // rows 0 .. CR-1, entry e at [e / 64][e % 64]
+      for (int dir = 0; dir < 3; ++dir) {
+        const size_t nops = ops_d[dir].size() / 3;
+        if (nops > (size_t)kHnOpRounds * 64) {
+          set_error("internal: more hanging-node lines in a batch than the plane kernel's record holds");
+          return MFGPU_EINVAL;
+        }
+        for (size_t e = 0; e < nops; ++e)
+          for (int w = 0; w < 3; ++w)
+            rec[(size_t)(CR + (dir * kHnOpRounds + (int)(e / 64)) * 3 + w) * 64 + e % 64] = ops_d[dir][e * 3 + w];
+      }
+      const uint32_t h0 = (uint32_t)copies.size() | ((uint32_t)(ops_d[0].size() / 3) << 16);
+      const uint32_t h1 = (uint32_t)(ops_d[1].size() / 3) | ((uint32_t)(ops_d[2].size() / 3) << 16);
+      for (int l = 0; l < 64; ++l) {
+        rec[(size_t)(HROWS - 2) * 64 + l] = h0;
+        rec[(size_t)(HROWS - 1) * 64 + l] = h1;
+      }
+    }
+  }
+  return 0;
+}
+
 int choose_kernel_and_plan(const mfgpu_desc &d, KernelChoice &kc, Plan &plan) {
   const bool general = !(d.flags & MFGPU_UNIFORM_J0), hn = (d.flags & MFGPU_HANGING_NODES) != 0;
   const bool colored = (d.flags & MFGPU_COLORED_SCATTER) != 0;
@@ -651,6 +751,7 @@ int mfgpu_plan_create(const mfgpu_desc *desc, mfgpu_plan **out) {
   mfgpu_plan *p = new mfgpu_plan();
   mfgpu::KernelChoice kc;
   int rc = mfgpu::choose_kernel_and_plan(*desc, kc, p->plan);
+  if (!rc && kc.planes) rc = mfgpu::build_plane_records(p->plan, desc->constraint_mask);
   if (rc) {
     delete p;
     return rc;
@@ -717,6 +818,9 @@ int64_t mfgpu_plan_array_u32(const mfgpu_plan *p, int what, const uint32_t **ptr
     case 10: v = &p->plan.s_idx; break;
     case 11: v = &p->plan.chunks; break;
     case 12: v = &p->plan.gstarts; break;
+    case 13: v = &p->plan.pr_dofs; break;
+    case 14: v = &p->plan.pr_idx; break;
+    case 15: v = &p->plan.pr_hn; break;
     default: mfgpu::set_error("bad array id"); return MFGPU_EINVAL;
   }
   *ptr = v->data();

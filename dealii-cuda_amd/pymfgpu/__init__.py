@@ -349,6 +349,10 @@ class Plan:
     s_idx = property(lambda s: s._u32(10))
     chunks = property(lambda s: s._u32(11).reshape(-1, 4))   # {sdofs position, count | k << 16, gstarts offset, offset in group}
     gstarts = property(lambda s: s._u32(12))
+    # plane plans (apply_planes3): fixed-size per-batch records
+    pr_dofs = property(lambda s: s._u32(13))   # dof lists, bit 31 = constrained
+    pr_idx = property(lambda s: s._u32(14))    # index runs
+    pr_hn = property(lambda s: s._u32(15))     # hanging-node records of the batches of masked cells
 
     @property
     def lmap(self):

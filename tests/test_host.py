@@ -185,6 +185,52 @@ def test_plane_plan_invariants_and_dataflow(p, n, kw):
     np.testing.assert_allclose(emulate_plan_vmult(od, plan, x, y0, twopass=True), ref, rtol=0, atol=1e-12 * np.abs(ref).max())
 
 
+def _masks3():
+    out = [t | (xyz << 3) for xyz in range(1, 8) for t in range(8)]
+    for e in (1 << 6, 1 << 7, 1 << 8, (1 << 6) | (1 << 5), (1 << 7) | (1 << 3), (1 << 8) | (1 << 4)):
+        out += [e | t for t in range(8)]
+    return out
+
+
+@pytest.mark.parametrize("p,n,kw", [(4, 3, {}), (4, 5, {}), (3, 4, {}), (2, 5, {}), (4, 4, dict(max_cells_per_batch=3))])
+def test_plane_records_dataflow_with_hanging_node_batches(p, n, kw):
+    """the fixed-size records apply_planes3 reads (dof lists, index runs, hanging-node records): numpy emulation of the
+    kernel's data flow -- private entries, line-by-line interpolation passes with the plain weight matrix, plain cell
+    kernel, transposed passes -- against the oracle's per-cell resolve_hanging_nodes, for every mask of the reference's
+    known-answer test placed on cells of a conforming mesh; and on conforming meshes without masks"""
+    from util import emulate_plane_records_vmult
+
+    od = o.uniform_mesh_desc(3, p, n)
+    rng = np.random.default_rng(p * 10 + n)
+    x, y0 = rng.standard_normal(od.n_dofs), rng.standard_normal(od.n_dofs)
+    for masked in (False, True):
+        if masked:
+            masks = _masks3()
+            cm = np.zeros(od.n_cells, dtype=np.uint32)
+            pick = rng.permutation(od.n_cells)[:od.n_cells * 3 // 4]
+            cm[pick] = np.array(masks, dtype=np.uint32)[np.arange(len(pick)) % len(masks)]
+            od.constraint_mask = cm
+        desc, keep = desc_from_oracle(od, kernel=mf.KERNEL_PLANES, **kw)
+        plan = mf.Plan(desc, keep)
+        assert (len(plan.pr_hn) > 0) == masked
+        ref = o.vmult(od, x)
+        np.testing.assert_allclose(emulate_plane_records_vmult(od, plan, x), ref, rtol=0, atol=1e-12 * np.abs(ref).max())
+        ref = o.vmult_add(od, y0, x)
+        np.testing.assert_allclose(emulate_plane_records_vmult(od, plan, x, y0), ref, rtol=0, atol=1e-12 * np.abs(ref).max())
+
+
+def test_plane_records_on_the_adaptive_mesh():
+    from util import emulate_plane_records_vmult, oracle_desc_from_mesh
+
+    mesh = mf.Mesh.adaptive(3, 4, 4)
+    od = oracle_desc_from_mesh(mesh)
+    plan = mf.Plan(mesh.desc, mesh)
+    assert len(plan.pr_hn) > 0
+    x = np.random.default_rng(1).standard_normal(od.n_dofs)
+    ref = o.vmult(od, x)
+    np.testing.assert_allclose(emulate_plane_records_vmult(od, plan, x), ref, rtol=0, atol=1e-12 * np.abs(ref).max())
+
+
 def test_plan_orphans_and_ragged_mesh():
     """dofs no cell touches (as hanging nodes are after substitution) + a disconnected, ragged mesh"""
     od = o.uniform_mesh_desc(2, 2, 4)

@@ -114,3 +114,93 @@ def deformed_oracle_desc(p, n, eps=0.12, seed=0, dtype=np.float64):
     jxw = od.JxW.astype(np.float64).reshape(nc, nd) / h ** 3 * det
     return o.Desc(3, p, od.n_dofs, od.loc2glob, jxw, np.linalg.inv(F), od.coefficient, od.constrained, None, dtype,
                   od.shape_values, od.shape_gradients)
+
+
+def emulate_plane_records_vmult(od: o.Desc, plan: "mf.Plan", src, dst_in=None):
+    """numpy emulation of apply_planes3's DATA FLOW on its fixed-size records (mfgpu_plan.cpp build_plane_records): dof
+    lists, index runs and -- for the batches of cells with a hanging-node mask -- the hanging-node records: private
+    copies of the constrained nodes, the interpolation passes x, y, z as plain W mat-vecs on the listed lines, the
+    PLAIN cell kernel (the oracle without masks), the transposed passes in reverse order, the sums back to the dofs'
+    entries; then the scatter and pass 2.  Checks the record builder (and hn_cell_lines), not the HIP code."""
+    n, nd = od.n, od.nd
+    n2 = n * n
+    JS, HS, PRIV = {3: (2, 3, 192), 4: (5, 6, 256), 5: (9, 9, 384)}[n]  # p_ji, p_hs, p_priv_max of mfgpu_internal.h
+    KGU = JS + HS
+    JI, NB, NT, NIW = JS * 64, KGU * 64, (64 // n) * n, (n2 + 1) // 2
+    CR, OR = PRIV // 64, 2
+    HROWS = CR + 3 * OR * 3 + 2
+    bco, order = plan.batch_cell_off, plan.cell_order
+    nbat = len(bco) - 1
+    bd = plan.pr_dofs.reshape(nbat, NB)
+    ixw = plan.pr_idx.reshape(nbat, NIW, NT)
+    hn = plan.pr_hn.reshape(-1, HROWS, 64)
+    nplain = nbat - hn.shape[0]
+    W = o.constraint_weights(od.degree).reshape(n, n)
+    hoff = plan.halo_off
+    add = dst_in is not None
+    dst = np.full(od.n_dofs, np.nan) if not add else np.array(dst_in, dtype=np.float64)
+    halo = np.full(int(hoff[-1]) + 1, np.nan)
+    halo[-1] = 0.0
+    pd = o.Desc(od.dim, od.degree, od.n_dofs, od.loc2glob[order], od.JxW[order], od.inv_jac[order],
+                od.coefficient[order], od.constrained, None, od.dtype, od.shape_values, od.shape_gradients, od.weights)
+    cm = None if od.constraint_mask is None else od.constraint_mask[order]
+    for b in range(nbat):
+        e = bd[b]
+        g = (e & 0x7fffffff).astype(np.int64)
+        con = (e >> 31).astype(bool)
+        ua = np.zeros(NB + PRIV)
+        ua[:NB] = np.where(con, 0.0, src[g])
+        copies, ops = [], [[], [], []]
+        if b >= nplain:
+            rec = hn[b - nplain]
+            ncopy, cnt = int(rec[HROWS - 2, 0] & 0xffff), [int(rec[HROWS - 2, 0] >> 16), int(rec[HROWS - 1, 0] & 0xffff), int(rec[HROWS - 1, 0] >> 16)]
+            assert np.all(rec[HROWS - 2] == rec[HROWS - 2, 0]) and np.all(rec[HROWS - 1] == rec[HROWS - 1, 0])
+            flat = rec[:CR].reshape(-1)[:ncopy]
+            copies = [(int(w >> 16), int(w & 0xffff)) for w in flat]
+            for d in range(3):
+                for k in range(cnt[d]):
+                    ww = rec[CR + (d * OR + k // 64) * 3:CR + (d * OR + k // 64) * 3 + 3, k % 64]
+                    ops[d].append([int((ww[t >> 1] >> (16 * (t & 1))) & 0xffff) for t in range(n)])
+            for dpos, spos in copies:
+                assert NB <= dpos < NB + PRIV and spos < NB
+                ua[dpos] = ua[spos]
+            for d in range(3):
+                touched = set()
+                for pos in ops[d]:
+                    assert all(NB <= q < NB + PRIV for q in pos) and not (touched & set(pos))  # lines of a pass are disjoint
+                    touched |= set(pos)
+                    ua[pos] = W @ ua[pos]
+        else:
+            assert cm is None or not cm[bco[b]:bco[b + 1]].any()
+        cells = np.arange(bco[b], bco[b + 1])
+        nc = len(cells)
+        pos = np.zeros((nc, nd), dtype=np.int64)
+        for c in range(nc):
+            for k in range(n):
+                w = ixw[b, :, c * n + k]
+                pos[c, n2 * k:n2 * (k + 1)] = np.stack([w & 0xffff, w >> 16], axis=1).reshape(-1)[:n2] // 8
+        assert pos.max() < NB + PRIV and not np.any(pos == NB - 1)
+        sub = o.Desc(pd.dim, pd.degree, pd.n_dofs, pd.loc2glob[cells], pd.JxW[cells], pd.inv_jac[cells],
+                     pd.coefficient[cells], pd.constrained, None, pd.dtype, pd.shape_values, pd.shape_gradients, pd.weights)
+        loc = o.cell_apply(sub, ua[pos])  # no masks: the hanging nodes are resolved on the batch array
+        acc = np.zeros(NB + PRIV)
+        np.add.at(acc, pos.reshape(-1), loc.reshape(-1))
+        for d in (2, 1, 0):
+            for q in ops[d]:
+                acc[q] = W.T @ acc[q]
+        for dpos, spos in copies:
+            acc[spos] += acc[dpos]
+        for q in range(JI):
+            assert not con[q] or acc[q] == 0.0  # (a constrained dof in a dst slot is padding: pass 2 rewrites it)
+            dst[g[q]] = (dst[g[q]] if add else 0.0) + acc[q]
+        halo[hoff[b]:hoff[b] + NB - JI] = acc[JI:NB]
+    sd, so, si = plan.sdofs, plan.s_off, plan.s_idx
+    for i in range(len(sd)):
+        gg = int(sd[i] & 0x7fffffff)
+        val = src[gg] if (sd[i] >> 31) else sum(halo[si[so[i]:so[i + 1]]])
+        dst[gg] = (dst[gg] if add else 0.0) + val
+    for oo in plan.orphans:
+        gg = int(oo & 0x7fffffff)
+        s = src[gg] if (oo >> 31) else 0.0
+        dst[gg] = (dst[gg] if add else 0.0) + s
+    return dst
