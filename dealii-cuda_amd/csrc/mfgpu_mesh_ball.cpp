@@ -141,7 +141,6 @@ struct BallMesh {
     fine.reserve(cells.size() << dim);
     for (const BallCell &c : cells) {
       // 3^dim lattice of the refined cell's vertices
-      const int L = dim == 3 ? 27 : 9;
       uint32_t lat[27];
       auto at = [&](int i, int j, int k) -> uint32_t & { return lat[i + 3 * j + 9 * k]; };
       const int kz = dim == 3 ? 2 : 1;
@@ -189,7 +188,6 @@ struct BallMesh {
             }
         at(1, 1, 1) = new_vertex(p, false);
       }
-      (void)L;
       for (int ck = 0; ck < kz; ++ck)
         for (int cj = 0; cj < 2; ++cj)
           for (int ci = 0; ci < 2; ++ci) {

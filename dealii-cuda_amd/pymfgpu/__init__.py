@@ -246,7 +246,8 @@ class Mesh:
         return out
 
     def renumber(self, new_index):
-        """DoFHandler::renumber_dofs on the stand-in mesh (in place); the desc pointers stay valid"""
+        """DoFHandler::renumber_dofs on the stand-in mesh (in place).  self.desc is refilled from the mesh: set the
+        tuning knobs (kernel, max_*_per_batch, ...) again afterwards."""
         ni = np.ascontiguousarray(new_index, dtype=np.uint32)
         assert ni.size == self.n_dofs
         _check(lib().mfgpu_mesh_renumber(self._h, ni.ctypes.data))
