@@ -92,17 +92,29 @@ public:
   typedef GpuVector<Number> VectorType;
   ~LevelOperatorGpu() { clear(); }
   void clear() {
-    mfgpu_destroy(handle);
+    mfgpu_level_destroy(lev);
+    lev = nullptr;
     handle = nullptr;
   }
-  void reinit(const MGDoFHandler<dim> &dof_handler, const MGConstrainedDoFs &, const unsigned int level_) {
+  // refinement_edge_indices: MGConstrainedDoFs::get_refinement_edge_indices(level); empty on globally refined meshes
+  void reinit(const MGDoFHandler<dim> &dof_handler, const MGConstrainedDoFs &, const unsigned int level_,
+              const std::vector<uint32_t> &refinement_edge_indices = std::vector<uint32_t>()) {
     clear();
     level = level_;
     mfgpu_desc d;
     check(mfgpu_mesh_desc(dof_handler.levels[level], &d), "mesh desc");
     if (d.number_type != number_type<Number>()) throw std::runtime_error("mesh / operator number type mismatch");
-    check(mfgpu_create(&d, &handle), "LevelOperatorGpu::reinit");
+    check(mfgpu_level_create(&d, refinement_edge_indices.data(), (uint32_t)refinement_edge_indices.size(), &lev),
+          "LevelOperatorGpu::reinit");
+    handle = mfgpu_level_operator(lev);  // owned by the level
     n_dofs = d.n_dofs;
+  }
+  // laplace_operator_gpu.h:306-352: the edge matrices of deal.II's Multigrid::set_edge_matrices
+  void vmult_interface_down(VectorType &dst, const VectorType &src) const {
+    check(mfgpu_level_vmult_interface_down(lev, dst.getData(), src.getDataRO(), nullptr), "vmult_interface_down");
+  }
+  void vmult_interface_up(VectorType &dst, const VectorType &src) const {
+    check(mfgpu_level_vmult_interface_up(lev, dst.getData(), src.getDataRO(), nullptr), "vmult_interface_up");
   }
   unsigned int m() const { return n_dofs; }
   unsigned int n() const { return n_dofs; }
@@ -125,6 +137,7 @@ public:
   unsigned int level = 0;
 
 private:
+  mfgpu_level *lev = nullptr;
   mfgpu_handle *handle = nullptr;
   unsigned int n_dofs = 0;
   std::shared_ptr<DiagonalMatrix<Number>> inverse_diagonal_matrix;

@@ -54,6 +54,8 @@ SYMBOLS = [
     "mfgpu_transfer_create", "mfgpu_transfer_create_from_meshes", "mfgpu_transfer_prolongate",
     "mfgpu_transfer_restrict_and_add", "mfgpu_transfer_memory_consumption", "mfgpu_transfer_destroy",
     "mfgpu_mesh_transfer_patches", "mfgpu_suggest_renumbering", "mfgpu_mesh_renumber",
+    "mfgpu_level_create", "mfgpu_level_operator", "mfgpu_level_vmult_interface_down", "mfgpu_level_vmult_interface_up",
+    "mfgpu_level_destroy",
 ]
 
 _lib = None
@@ -134,6 +136,13 @@ def lib():
         L.mfgpu_mesh_transfer_patches.restype = C.c_int64
         L.mfgpu_suggest_renumbering.argtypes = [C.POINTER(Desc), C.c_void_p]
         L.mfgpu_mesh_renumber.argtypes = [C.c_void_p, C.c_void_p]
+        L.mfgpu_level_create.argtypes = [C.POINTER(Desc), C.c_void_p, C.c_uint32, C.POINTER(C.c_void_p)]
+        L.mfgpu_level_operator.argtypes = [C.c_void_p]
+        L.mfgpu_level_operator.restype = C.c_void_p
+        L.mfgpu_level_vmult_interface_down.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
+        L.mfgpu_level_vmult_interface_up.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
+        L.mfgpu_level_destroy.argtypes = [C.c_void_p]
+        L.mfgpu_level_destroy.restype = None
         L.mfgpu_transfer_destroy.argtypes = [C.c_void_p]
         L.mfgpu_transfer_destroy.restype = None
         _lib = L
@@ -505,6 +514,32 @@ class Operator:
         ms, nv = C.c_double(), C.c_uint64()
         _check(lib().mfgpu_profile_read(self._h, C.byref(ms), C.byref(nv)))
         return ms.value, int(nv.value)
+
+
+class Level:
+    """Level operator with refinement edges + the interface matrices (mfgpu_level_*)."""
+
+    def __init__(self, desc: Desc, edge_dofs, keep=None):
+        self._keep = keep
+        e = np.ascontiguousarray(edge_dofs, dtype=np.uint32)
+        h = C.c_void_p()
+        _check(lib().mfgpu_level_create(C.byref(desc), e.ctypes.data if e.size else None, e.size, C.byref(h)))
+        self._h = h
+        self.number_type = desc.number_type
+
+    def vmult(self, dst, src, stream=None):
+        _check(lib().mfgpu_vmult(lib().mfgpu_level_operator(self._h), _ptr(dst), _ptr(src), stream))
+
+    def vmult_interface_down(self, dst, src, stream=None):
+        _check(lib().mfgpu_level_vmult_interface_down(self._h, _ptr(dst), _ptr(src), stream))
+
+    def vmult_interface_up(self, dst, src, stream=None):
+        _check(lib().mfgpu_level_vmult_interface_up(self._h, _ptr(dst), _ptr(src), stream))
+
+    def __del__(self):
+        if getattr(self, "_h", None) and _lib is not None:
+            _lib.mfgpu_level_destroy(self._h)
+            self._h = None
 
 
 class Transfer:

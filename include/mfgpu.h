@@ -257,6 +257,18 @@ int mfgpu_transfer_restrict_and_add(mfgpu_transfer *t, void *dst_coarse_dev, con
 size_t mfgpu_transfer_memory_consumption(const mfgpu_transfer *t); /* :333-347 */
 void mfgpu_transfer_destroy(mfgpu_transfer *t);
 
+/* Level operator with refinement edges (laplace_operator_gpu.h:154-186, 306-352): `desc` describes the level mesh with
+ * the level's Dirichlet dofs as constrained_dofs (no hanging nodes on a level mesh, :174-176), edge_dofs are the level's
+ * refinement-edge dofs (MGConstrainedDoFs::get_refinement_edge_indices).  mfgpu_level_operator is the level matrix
+ * (constrained rows = Dirichlet + edge dofs: vmult, inverse diagonal ... through the ordinary calls; owned by the level);
+ * the interface matrices are what deal.II's Multigrid::set_edge_matrices takes (poisson_mg.cu:367-375).               */
+typedef struct mfgpu_level mfgpu_level;
+int mfgpu_level_create(const mfgpu_desc *desc, const uint32_t *edge_dofs, uint32_t n_edge, mfgpu_level **out);
+mfgpu_handle *mfgpu_level_operator(mfgpu_level *level);
+int mfgpu_level_vmult_interface_down(mfgpu_level *level, void *dst_dev, const void *src_dev, void *stream); /* :306-330 */
+int mfgpu_level_vmult_interface_up(mfgpu_level *level, void *dst_dev, const void *src_dev, void *stream);   /* :332-352 */
+void mfgpu_level_destroy(mfgpu_level *level);
+
 /* ---- deal.II stand-in for the setup side (host only) --------------------------------------
  * Produces what Triangulation + DoFHandler + ConstraintMatrix + FEValues + ShapeInfo hand to
  * MatrixFreeGpu::reinit, for the meshes bmop uses (bmop_common.h:108-120).                    */
