@@ -530,6 +530,9 @@ class Level:
     def vmult(self, dst, src, stream=None):
         _check(lib().mfgpu_vmult(lib().mfgpu_level_operator(self._h), _ptr(dst), _ptr(src), stream))
 
+    def compute_inverse_diagonal(self, inv_diag, stream=None):
+        _check(lib().mfgpu_compute_inverse_diagonal(lib().mfgpu_level_operator(self._h), _ptr(inv_diag), stream))
+
     def vmult_interface_down(self, dst, src, stream=None):
         _check(lib().mfgpu_level_vmult_interface_down(self._h, _ptr(dst), _ptr(src), stream))
 
