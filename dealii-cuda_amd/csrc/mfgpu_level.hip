@@ -28,7 +28,19 @@ struct mfgpu_level {
   void *tmp_x = nullptr, *tmp_y = nullptr;
 };
 
+// index pairs on the device: copy_to_mg / copy_from_mg (mg_transfer_matrix_free_gpu.cu:690-760, copy_indices)
+struct mfgpu_index_pairs {
+  uint32_t *d_dst = nullptr, *d_src = nullptr;
+  uint32_t n = 0;
+};
+
 namespace {
+
+template <typename T>
+__global__ void copy_pairs_kernel(T *dst, const T *src, const uint32_t *di, const uint32_t *si, uint32_t n) {
+  const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) dst[di[i]] = src[si[i]];
+}
 
 template <typename T>
 __global__ void set_indexed_kernel(T *v, const uint32_t *idx, uint32_t n, T value) {
@@ -141,6 +153,47 @@ int mfgpu_level_vmult_interface_up(mfgpu_level *L, void *dst, const void *src, v
   }
   return L->number_type == MFGPU_F64 ? interface_typed<double>(L, false, (double *)dst, (const double *)src, (hipStream_t)stream)
                                      : interface_typed<float>(L, false, (float *)dst, (const float *)src, (hipStream_t)stream);
+}
+
+int mfgpu_index_pairs_create(const uint32_t *dst_idx, const uint32_t *src_idx, uint32_t n, mfgpu_index_pairs **out) {
+  if (!out || (n && (!dst_idx || !src_idx))) {
+    mfgpu::set_error("mfgpu_index_pairs_create: null argument");
+    return MFGPU_EINVAL;
+  }
+  mfgpu_index_pairs *p = new mfgpu_index_pairs();
+  p->n = n;
+  if (n && (hipMalloc((void **)&p->d_dst, (size_t)n * 4) != hipSuccess || hipMalloc((void **)&p->d_src, (size_t)n * 4) != hipSuccess ||
+            hipMemcpy(p->d_dst, dst_idx, (size_t)n * 4, hipMemcpyHostToDevice) != hipSuccess ||
+            hipMemcpy(p->d_src, src_idx, (size_t)n * 4, hipMemcpyHostToDevice) != hipSuccess)) {
+    mfgpu::set_error("mfgpu_index_pairs_create: device allocation failed");
+    mfgpu_index_pairs_destroy(p);
+    return MFGPU_ENOMEM;
+  }
+  *out = p;
+  return 0;
+}
+
+int mfgpu_vec_copy_pairs(const mfgpu_index_pairs *p, void *dst, const void *src, int number_type, void *stream) {
+  if (!p || !dst || !src) {
+    mfgpu::set_error("mfgpu_vec_copy_pairs: null argument");
+    return MFGPU_EINVAL;
+  }
+  if (p->n == 0) return 0;
+  const unsigned grid = (p->n + 255) / 256;
+  if (number_type == MFGPU_F64)
+    hipLaunchKernelGGL(copy_pairs_kernel<double>, dim3(grid), dim3(256), 0, (hipStream_t)stream, (double *)dst,
+                       (const double *)src, p->d_dst, p->d_src, p->n);
+  else
+    hipLaunchKernelGGL(copy_pairs_kernel<float>, dim3(grid), dim3(256), 0, (hipStream_t)stream, (float *)dst,
+                       (const float *)src, p->d_dst, p->d_src, p->n);
+  return hipGetLastError() == hipSuccess ? 0 : MFGPU_EHIP;
+}
+
+void mfgpu_index_pairs_destroy(mfgpu_index_pairs *p) {
+  if (!p) return;
+  hipFree(p->d_dst);
+  hipFree(p->d_src);
+  delete p;
 }
 
 void mfgpu_level_destroy(mfgpu_level *L) {

@@ -37,7 +37,7 @@ struct Mesh {
 };
 
 int build_uniform(Mesh &M, const uint32_t *nper, double lo, double hi, uint32_t sb, uint32_t se);
-int build_adaptive(Mesh &M, int n_ref);
+int build_adaptive(Mesh &M, int n_ref, bool balance_vertices);
 int build_ball(Mesh &M, int n_ref);
 // (p+1)^dim dofs of every coarse cell and (2p+1)^dim dofs of its children's patch, lexicographic (mg_transfer_matrix_
 // free_gpu.h:246 level_dof_indices); fine must be the global refinement of coarse

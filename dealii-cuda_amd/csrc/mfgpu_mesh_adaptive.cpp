@@ -32,6 +32,7 @@ struct Tree {
   int dim;
   std::unordered_set<uint64_t> active;  // leaves
   int max_level = 0;
+  bool balance_vertices = false;  // Triangulation::limit_level_difference_at_vertices (poisson_mg.cu:131)
 
   bool is_active(int l, const uint32_t *c) const { return active.count(ckey(l, c)) != 0; }
 
@@ -88,8 +89,11 @@ struct Tree {
           for (int oy = -1; oy <= 1; ++oy)
             for (int oz = (dim == 3 ? -1 : 0); oz <= (dim == 3 ? 1 : 0); ++oz) {
               const int nz = (ox != 0) + (oy != 0) + (oz != 0);
-              if (nz == 0 || nz > 2) continue;      // faces (1) and edges (2); not vertices
-              if (dim == 2 && nz == 2) continue;    // 2D: faces only
+              if (nz == 0) continue;
+              if (!balance_vertices) {
+                if (nz > 2) continue;               // faces (1) and edges (2); not vertices
+                if (dim == 2 && nz == 2) continue;  // 2D: faces only
+              }
               int64_t ci[3] = {(int64_t)c.c[0] + ox, (int64_t)c.c[1] + oy, (int64_t)c.c[2] + oz};
               const int lv = covering_level(c.level, ci);
               if (lv >= 0 && lv < c.level) {
@@ -176,7 +180,7 @@ DofKey dof_key(int dim, int p, const Cell &c, const int *idx) {
 
 }  // namespace
 
-int build_adaptive(Mesh &M, int n_ref) {
+int build_adaptive(Mesh &M, int n_ref, bool balance_vertices) {
   const int dim = M.dim, p = M.degree, n = p + 1, nd = ipow(n, dim);
   if (n_ref < 0 || n_ref > 12) {
     set_error("mfgpu_mesh_create_adaptive: n_ref out of range");
@@ -185,6 +189,7 @@ int build_adaptive(Mesh &M, int n_ref) {
   M.init_tables();
   Tree T;
   T.dim = dim;
+  T.balance_vertices = balance_vertices;
   {
     uint32_t c0[3] = {0, 0, 0};
     T.active.insert(ckey(0, c0));
@@ -476,7 +481,26 @@ int mfgpu_mesh_create_adaptive(int dim, int degree, int n_ref, int number_type, 
   m->mesh.dim = dim;
   m->mesh.degree = degree;
   m->mesh.number_type = number_type;
-  int rc = mfgpu::build_adaptive(m->mesh, n_ref);
+  int rc = mfgpu::build_adaptive(m->mesh, n_ref, false);
+  if (rc) {
+    delete m;
+    return rc;
+  }
+  *out = m;
+  return 0;
+}
+
+int mfgpu_mesh_create_adaptive_mg(int dim, int degree, int n_ref, int number_type, mfgpu_mesh **out) {
+  if (!out || (dim != 2 && dim != 3) || degree < 1 || degree > 6 ||
+      (number_type != MFGPU_F64 && number_type != MFGPU_F32)) {
+    mfgpu::set_error("mfgpu_mesh_create_adaptive_mg: bad argument");
+    return MFGPU_EINVAL;
+  }
+  mfgpu_mesh *m = new mfgpu_mesh();
+  m->mesh.dim = dim;
+  m->mesh.degree = degree;
+  m->mesh.number_type = number_type;
+  int rc = mfgpu::build_adaptive(m->mesh, n_ref, true);
   if (rc) {
     delete m;
     return rc;

@@ -4,7 +4,8 @@
 // classes are the stand-ins of mfgpu_shim.h / mfgpu_shim_mg.h; everything on the device goes through the C-ABI.  The
 // right-hand side is A x* for a known x*, so the driver checks its own answer.
 // Output:  dim  degree  n_dofs  levels  cg_iterations  wall_seconds  rel_error
-// usage: poisson-mg-<dim>d-p<k> n_ref          (-DBALL_GRID: the BALL domain)
+// usage: poisson-mg-<dim>d-p<k> n_ref          (-DBALL_GRID: the BALL domain; -DADAPTIVE_GRID: the pseudo-adaptive
+// mesh with hanging nodes, local smoothing with refinement-edge matrices, poisson_mg.cu:365-375)
 #include <chrono>
 #include <cstdio>
 #include <cstdlib>
@@ -59,8 +60,10 @@ template <int dim, int fe_degree>
 int run(int n_ref) {
   typedef LevelOperatorGpu<dim, fe_degree, number> LevelMatrixType;
   Triangulation<dim> triangulation;
-#ifdef BALL_GRID
+#if defined(BALL_GRID)
   bmop_setup_mesh(triangulation, BALL, false, n_ref);
+#elif defined(ADAPTIVE_GRID)
+  bmop_setup_mesh(triangulation, CUBE, true, n_ref);
 #else
   bmop_setup_mesh(triangulation, CUBE, false, n_ref);
 #endif
@@ -76,7 +79,11 @@ int run(int n_ref) {
     mg_matrices[level].reinit(dof_handler, mg_constrained_dofs, level);
     mg_matrices[level].compute_diagonal();
   }
-  const LevelMatrixType &system_matrix = mg_matrices[nlevels - 1];  // global refinement: the finest level
+  // the system matrix: on a globally refined mesh the finest level's; on the adaptive mesh the active cells' operator
+  // with hanging nodes
+  LevelMatrixType active_matrix;
+  if (dof_handler.is_adaptive()) active_matrix.reinit_active(dof_handler);
+  const LevelMatrixType &system_matrix = dof_handler.is_adaptive() ? active_matrix : mg_matrices[nlevels - 1];
   const unsigned int N = system_matrix.n();
 
   MGTransferMatrixFreeGpu<dim, number> mg_transfer(mg_constrained_dofs);

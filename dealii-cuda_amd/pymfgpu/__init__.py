@@ -55,7 +55,9 @@ SYMBOLS = [
     "mfgpu_transfer_restrict_and_add", "mfgpu_transfer_memory_consumption", "mfgpu_transfer_destroy",
     "mfgpu_mesh_transfer_patches", "mfgpu_suggest_renumbering", "mfgpu_mesh_renumber",
     "mfgpu_level_create", "mfgpu_level_operator", "mfgpu_level_vmult_interface_down", "mfgpu_level_vmult_interface_up",
-    "mfgpu_level_destroy",
+    "mfgpu_level_destroy", "mfgpu_index_pairs_create", "mfgpu_vec_copy_pairs", "mfgpu_index_pairs_destroy",
+    "mfgpu_mesh_create_adaptive_mg", "mfgpu_mg_hierarchy_create", "mfgpu_mg_n_levels", "mfgpu_mg_level_mesh",
+    "mfgpu_mg_edge_dofs", "mfgpu_mg_copy_pairs", "mfgpu_mg_transfer_arrays", "mfgpu_mg_hierarchy_destroy",
 ]
 
 _lib = None
@@ -141,6 +143,23 @@ def lib():
         L.mfgpu_level_operator.restype = C.c_void_p
         L.mfgpu_level_vmult_interface_down.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
         L.mfgpu_level_vmult_interface_up.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
+        L.mfgpu_mesh_create_adaptive_mg.argtypes = [C.c_int, C.c_int, C.c_int, C.c_int, C.POINTER(C.c_void_p)]
+        L.mfgpu_mg_hierarchy_create.argtypes = [C.c_void_p, C.POINTER(C.c_void_p)]
+        L.mfgpu_mg_n_levels.argtypes = [C.c_void_p]
+        L.mfgpu_mg_level_mesh.argtypes = [C.c_void_p, C.c_int]
+        L.mfgpu_mg_level_mesh.restype = C.c_void_p
+        L.mfgpu_mg_edge_dofs.argtypes = [C.c_void_p, C.c_int, C.POINTER(C.c_void_p)]
+        L.mfgpu_mg_edge_dofs.restype = C.c_int64
+        L.mfgpu_mg_copy_pairs.argtypes = [C.c_void_p, C.c_int, C.POINTER(C.c_void_p), C.POINTER(C.c_void_p)]
+        L.mfgpu_mg_copy_pairs.restype = C.c_int64
+        L.mfgpu_mg_transfer_arrays.argtypes = [C.c_void_p, C.c_int, C.POINTER(C.c_void_p), C.POINTER(C.c_void_p)]
+        L.mfgpu_mg_transfer_arrays.restype = C.c_int64
+        L.mfgpu_mg_hierarchy_destroy.argtypes = [C.c_void_p]
+        L.mfgpu_mg_hierarchy_destroy.restype = None
+        L.mfgpu_index_pairs_create.argtypes = [C.c_void_p, C.c_void_p, C.c_uint32, C.POINTER(C.c_void_p)]
+        L.mfgpu_vec_copy_pairs.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p]
+        L.mfgpu_index_pairs_destroy.argtypes = [C.c_void_p]
+        L.mfgpu_index_pairs_destroy.restype = None
         L.mfgpu_level_destroy.argtypes = [C.c_void_p]
         L.mfgpu_level_destroy.restype = None
         L.mfgpu_transfer_destroy.argtypes = [C.c_void_p]
@@ -190,6 +209,13 @@ class Mesh:
         return cls(h)
 
     @classmethod
+    def adaptive_mg(cls, dim, degree, n_ref, number_type=F64):
+        """the ADAPTIVE_GRID recipe with 2:1 balance over vertices too (what the multigrid hierarchy needs)"""
+        h = C.c_void_p()
+        _check(lib().mfgpu_mesh_create_adaptive_mg(dim, degree, n_ref, number_type, C.byref(h)))
+        return cls(h)
+
+    @classmethod
     def ball(cls, dim, degree, n_ref, number_type=F64):
         h = C.c_void_p()
         _check(lib().mfgpu_mesh_create_ball(dim, degree, n_ref, number_type, C.byref(h)))
@@ -208,8 +234,8 @@ class Mesh:
         return _view(p.value, cnt, np.uint32).reshape(-1, 4).copy()
 
     def __del__(self):
-        if getattr(self, "_h", None) and _lib is not None:  # _lib is None at interpreter shutdown
-            _lib.mfgpu_mesh_destroy(self._h)
+        if getattr(self, "_h", None) and _lib is not None and getattr(self, "_owner", None) is None:
+            _lib.mfgpu_mesh_destroy(self._h)  # (_lib is None at interpreter shutdown)
             self._h = None
 
     # ---- numpy views of the description arrays (valid while the mesh lives)
@@ -514,6 +540,45 @@ class Operator:
         ms, nv = C.c_double(), C.c_uint64()
         _check(lib().mfgpu_profile_read(self._h, C.byref(ms), C.byref(nv)))
         return ms.value, int(nv.value)
+
+
+class MgHierarchy:
+    """Level hierarchy of an adaptive stand-in mesh (mfgpu_mg_*): level meshes, refinement-edge dofs, transfer arrays,
+    copy_to_mg pairs.  Host only."""
+
+    def __init__(self, mesh: "Mesh"):
+        h = C.c_void_p()
+        _check(lib().mfgpu_mg_hierarchy_create(mesh._h, C.byref(h)))
+        self._h = h
+        self.n_levels = int(lib().mfgpu_mg_n_levels(h))
+
+    def level_mesh(self, level):
+        m = Mesh.__new__(Mesh)
+        m._owner = self  # borrowed: the level meshes belong to the hierarchy (Mesh.__del__ leaves them alone)
+        m._h = C.c_void_p(lib().mfgpu_mg_level_mesh(self._h, level))
+        m.desc = Desc()
+        _check(lib().mfgpu_mesh_desc(m._h, C.byref(m.desc)))
+        return m
+
+    def edge_dofs(self, level):
+        p = C.c_void_p()
+        n = lib().mfgpu_mg_edge_dofs(self._h, level, C.byref(p))
+        return _view(p.value, n, np.uint32).copy()
+
+    def copy_pairs(self, level):
+        a, b = C.c_void_p(), C.c_void_p()
+        n = lib().mfgpu_mg_copy_pairs(self._h, level, C.byref(a), C.byref(b))
+        return _view(a.value, n, np.uint32).copy(), _view(b.value, n, np.uint32).copy()
+
+    def transfer_arrays(self, level, nd, nfd):
+        a, b = C.c_void_p(), C.c_void_p()
+        n = lib().mfgpu_mg_transfer_arrays(self._h, level, C.byref(a), C.byref(b))
+        return _view(a.value, n * nd, np.uint32).reshape(n, nd).copy(), _view(b.value, n * nfd, np.uint32).reshape(n, nfd).copy()
+
+    def __del__(self):
+        if getattr(self, "_h", None) and _lib is not None:
+            _lib.mfgpu_mg_hierarchy_destroy(self._h)
+            self._h = None
 
 
 class Level:

@@ -269,6 +269,13 @@ int mfgpu_level_vmult_interface_down(mfgpu_level *level, void *dst_dev, const vo
 int mfgpu_level_vmult_interface_up(mfgpu_level *level, void *dst_dev, const void *src_dev, void *stream);   /* :332-352 */
 void mfgpu_level_destroy(mfgpu_level *level);
 
+/* copy_to_mg / copy_from_mg (mg_transfer_matrix_free_gpu.cu:690-760): dst[dst_idx[i]] = src[src_idx[i]] for the index
+ * pairs of copy_indices (active dof <-> level dof), kept on the device                                              */
+typedef struct mfgpu_index_pairs mfgpu_index_pairs;
+int mfgpu_index_pairs_create(const uint32_t *dst_idx, const uint32_t *src_idx, uint32_t n, mfgpu_index_pairs **out);
+int mfgpu_vec_copy_pairs(const mfgpu_index_pairs *p, void *dst_dev, const void *src_dev, int number_type, void *stream);
+void mfgpu_index_pairs_destroy(mfgpu_index_pairs *p);
+
 /* ---- deal.II stand-in for the setup side (host only) --------------------------------------
  * Produces what Triangulation + DoFHandler + ConstraintMatrix + FEValues + ShapeInfo hand to
  * MatrixFreeGpu::reinit, for the meshes bmop uses (bmop_common.h:108-120).                    */
@@ -296,6 +303,23 @@ int64_t mfgpu_mesh_transfer_patches(const mfgpu_mesh *coarse, const mfgpu_mesh *
                                     uint32_t *fine_patch_dofs);
 /* DoFHandler::renumber_dofs on the stand-in: loc2glob, constrained dofs, dof coordinates, interface planes */
 int mfgpu_mesh_renumber(mfgpu_mesh *m, const uint32_t *new_index);
+/* the same recipe with Triangulation::limit_level_difference_at_vertices (2:1 over vertices too), which the reference's
+ * multigrid programs set (poisson_mg.cu:131): required by mfgpu_mg_hierarchy_create                                  */
+int mfgpu_mesh_create_adaptive_mg(int dim, int degree, int n_ref, int number_type, mfgpu_mesh **out);
+/* Multigrid level hierarchy of an adaptive octree stand-in mesh (host only): what distribute_mg_dofs +
+ * MGConstrainedDoFs + MGTransferMatrixFreeGpu::build provide on a locally refined mesh (poisson_mg.cu:152,199-209,
+ * 325-326).  Level l = all cells of level l; see csrc/mfgpu_mg_hierarchy.cpp.  The level meshes belong to the hierarchy. */
+typedef struct mfgpu_mg_hierarchy mfgpu_mg_hierarchy;
+int mfgpu_mg_hierarchy_create(const mfgpu_mesh *adaptive, mfgpu_mg_hierarchy **out);
+int mfgpu_mg_n_levels(const mfgpu_mg_hierarchy *h);
+const mfgpu_mesh *mfgpu_mg_level_mesh(const mfgpu_mg_hierarchy *h, int level);
+int64_t mfgpu_mg_edge_dofs(const mfgpu_mg_hierarchy *h, int level, const uint32_t **ptr); /* refinement-edge dofs */
+/* copy_indices of the level: returns n, (active dof, level dof) pairs */
+int64_t mfgpu_mg_copy_pairs(const mfgpu_mg_hierarchy *h, int level, const uint32_t **active_dofs, const uint32_t **level_dofs);
+/* arrays for mfgpu_transfer_create(level - 1 -> level): returns the number of refined cells of level - 1 */
+int64_t mfgpu_mg_transfer_arrays(const mfgpu_mg_hierarchy *h, int level, const uint32_t **coarse_cell_dofs,
+                                 const uint32_t **fine_patch_dofs);
+void mfgpu_mg_hierarchy_destroy(mfgpu_mg_hierarchy *h);
 /* same setup from an explicit one-irregular set of octree leaves (level, cx, cy, cz) x n_leaves on
  * hyper_cube(-1,1): lets tests build the awkward small cases of test_hanging_nodes_gpu.cu:297-331 */
 int mfgpu_mesh_create_from_leaves(int dim, int degree, const uint32_t *leaves, uint32_t n_leaves,

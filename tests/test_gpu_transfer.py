@@ -208,6 +208,17 @@ def test_poisson_mg_driver_binaries():
             assert int(f[2]) == ndofs
         assert int(f[3]) == int(arg) + 1 and float(f[6]) < 1e-8
         its[(exe, arg)] = int(f[4])
+    # ADAPTIVE_GRID: local smoothing with refinement-edge matrices on the pseudo-adaptive mesh (vertex-balanced), the
+    # active-mesh operator with hanging nodes as system matrix
+    for exe, args in (("poisson-mg-2d-p2-adaptive", ("4", "6")), ("poisson-mg-3d-p4-adaptive", ("4", "5"))):
+        got = []
+        for arg in args:
+            out = subprocess.run([os.path.join(b, exe), arg], capture_output=True, text=True, timeout=300)
+            assert out.returncode == 0, out.stdout + out.stderr
+            f = out.stdout.split()
+            assert float(f[6]) < 1e-8 and int(f[3]) >= 5
+            got.append(int(f[4]))
+        assert got[1] <= got[0] + 3 <= 18, got
     # level-independent iteration counts
     assert its[("poisson-mg-2d-p2", "7")] <= its[("poisson-mg-2d-p2", "5")] + 2 <= 16
     assert its[("poisson-mg-3d-p4", "4")] <= its[("poisson-mg-3d-p4", "3")] + 2 <= 16
