@@ -21,12 +21,47 @@ for _p in (ROOT, os.path.join(ROOT, "dealii-cuda_amd")):
     if _p not in sys.path:
         sys.path.insert(0, _p)
 
-import torch  # noqa: E402  (FIRST: libmfgpu.so must bind to the HIP runtime torch already loaded)
-import torch.distributed as dist  # noqa: E402
-import numpy as np  # noqa: E402
+# torch / numpy / pymfgpu are imported by _imports(), AFTER the launcher branch of main(): the parent of a multi-GPU
+# run must not load anything that could touch the GPU before it has started its children.
+torch = dist = np = mf = SlabExchange = slab_ranges = None
 
-import pymfgpu as mf  # noqa: E402
-from pymfgpu.parallel import SlabExchange, slab_ranges  # noqa: E402
+
+def _imports():
+    global torch, dist, np, mf, SlabExchange, slab_ranges
+    import torch as _torch  # FIRST: libmfgpu.so must bind to the HIP runtime torch already loaded
+    import torch.distributed as _dist
+    import numpy as _np
+    import pymfgpu as _mf
+    from pymfgpu.parallel import SlabExchange as _SE, slab_ranges as _sr
+    torch, dist, np, mf, SlabExchange, slab_ranges = _torch, _dist, _np, _mf, _SE, _sr
+
+
+def launch_ranks(n, argv):
+    """`python bench.py --gpus N` with no WORLD_SIZE in the environment (the way the driver starts it): start N fresh
+    rank processes (torch.distributed.run, one per GPU, rendezvous on 127.0.0.1) as CHILDREN of this process, which
+    has made no GPU call and makes none; relay rank 0's JSON line; exit non-zero if the launcher or any rank does."""
+    import socket
+    import subprocess
+    with socket.socket() as so:
+        so.bind(("127.0.0.1", 0))
+        port = so.getsockname()[1]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")  # dmabuf IPC only on this pool (RCCL needs it)
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n}",
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + list(argv)
+    print(f"[bench] no WORLD_SIZE: launching {n} ranks: {' '.join(cmd)}", file=sys.stderr, flush=True)
+    pr = subprocess.run(cmd, env=env, stdout=subprocess.PIPE, text=True)
+    line = None
+    for ln in pr.stdout.splitlines():
+        if ln.startswith("{") and '"metric"' in ln:
+            line = ln
+        else:
+            print(ln, file=sys.stderr)
+    if pr.returncode != 0 or line is None:
+        print(f"[bench] multi-GPU run failed: launcher exit code {pr.returncode}"
+              + ("" if line is not None else ", no result line from rank 0"), file=sys.stderr, flush=True)
+        raise SystemExit(pr.returncode if pr.returncode != 0 else 1)
+    print(line, flush=True)
 
 HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
 
@@ -47,10 +82,15 @@ def csrc_sha16():
     return hsh.hexdigest()[:16]
 
 
+def parity_vector(n_dofs):
+    """the vector of the GPU-vs-CPU figure: seeded, non-constant, every cell contributes"""
+    return np.random.default_rng(20240229).standard_normal(n_dofs)
+
+
 def cpu_baseline(args, budget_s=12.0):
     """oracle/cpu_ref.c (a port, not the reference: the reference CPU path needs deal.II) on the host cores: SAME mesh
     as the GPU run by default, same protocol (bmop-cpu.cc:137-155), bounded sample: as many vmults as fit in
-    ~budget_s (>= 2).  Also returns the result of ONE apply to the vector of 0.1s, for the GPU-vs-CPU check."""
+    ~budget_s (>= 2).  Also returns the result of ONE apply to parity_vector(), for the GPU-vs-CPU check."""
     from oracle import cpu_ref
     from oracle import mf_oracle as o
 
@@ -63,8 +103,11 @@ def cpu_baseline(args, budget_s=12.0):
     ref = cpu_ref.CpuRef(od, cpu_ref.structured_cell_colors([n] * 3))
     share = cpu_ref.cpu_share()
     cpu_ref.set_threads(share)  # one thread per CPU this process owns (affinity mask / cgroup quota)
+    # warm-up (page faults, thread pool) on a seeded RANDOM vector, kept for the parity figure: the protocol's vector
+    # of 0.1s lies in the operator's kernel away from the boundary (grad const = 0) and would test 11 % of the cells
+    x0 = parity_vector(mesh.n_dofs)
+    y1 = ref.vmult(x0)
     x = np.full(mesh.n_dofs, 0.1)
-    y1 = ref.vmult(x)  # warm-up (page faults, thread pool); kept for the parity figure
     t0 = time.perf_counter()
     k = 0
     while True:
@@ -114,11 +157,17 @@ def main():
                     help="bmop -DBALL_GRID: hyper_ball with NREF global refinements (unstructured, general-geometry path; 1 GPU)")
     args = ap.parse_args()
 
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        launch_ranks(args.gpus, sys.argv[1:])  # before any import that could touch the GPU
+        return
+    _imports()
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if world != args.gpus:
-        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run")
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
+    if os.environ.get("MFGPU_BENCH_ECHO_RANK"):  # tests/test_bench_launcher.py
+        print(f"[bench] rank {rank} of {world} started", file=sys.stderr, flush=True)
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU (the HIP path has no CPU fallback)")
     torch.cuda.set_device(local_rank)
@@ -270,6 +319,7 @@ def main():
         dst, src = src, dst
         op.vmult(dst, src, stream)
     k_ms, n_v = op.profile_read()
+    p2_ms = op.profile_read_pass2()
     op.profile_enable(False)
     launches = n_v * stats["n_launches"]
     b_alg_loc = algorithmic_bytes(N_loc, mesh.n_cells, nd, s)
@@ -280,7 +330,7 @@ def main():
     # HBM traffic of the dominant kernel: NOT measured by this run (PMC counters need rocprofv3 passes of their own,
     # tools/profile_bench.sh); copied from the committed summary of the last such passes IF it was taken on this
     # workload, kernel and library source (hash of csrc/), else null.  `traffic_source` says where it came from.
-    traffic, traffic_source = None, None
+    traffic, traffic_step, traffic_source = None, None, None
     tj = os.path.join(ROOT, "profiles", "traffic_latest.json")
     if os.path.exists(tj):
         try:
@@ -290,13 +340,14 @@ def main():
                     and not args.adaptive and not args.colored and not args.batch_cells and not args.batch_dofs
                     and not general and args.kernel == "auto" and not args.renumber):
                 traffic = tr["hbm_bytes_per_launch"]
+                traffic_step = tr.get("step_hbm_bytes_per_vmult")
                 traffic_source = {"file": "profiles/traffic_latest.json", "profile": tr.get("profile"),
                                   "csrc_sha16": tr.get("csrc_sha16")}
         except Exception:
             traffic = None
 
     out = {
-        "metric": "DoFs/s on 100x Laplace vmult (bmop), p=4 3D uniform",
+        "metric": f"DoFs/s on {args.steps}x Laplace vmult (bmop), p={p} 3D uniform",
         "value": n_dofs_glob * args.steps / t,
         "unit": "DoFs/s",
         "n_gpus": world,
@@ -323,20 +374,27 @@ def main():
                    "parallelism": f"slab{world}" + (f"/{args.mode}" if world > 1 else ""),
                    "dof_numbering": "batch-major (mfgpu_suggest_renumbering)" if args.renumber else "caller's (lexicographic)",
                    "plan": stats, "finite": finite},
-        "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                     "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_source,
+        # `achieved` / `frac`: the vmult's algorithmic bytes over the time of ALL its kernels (cell loop + pass 2, HIP
+        # events on the launch stream) -- pass 2 writes the shared and constrained dofs, so the cell-loop kernel alone
+        # does not move all of B_alg; its own figure is `cell_kernel_frac`, the whole step's (launch gaps included)
+        # `step_frac`.  `traffic`: PMC bytes of the cell-loop kernel per launch, `traffic_step`: of all kernels of a vmult.
+        "roofline": {"bound": "hbm", "achieved": b_alg_loc * n_v / ((k_ms + p2_ms) * 1e-3) / 1e9, "peak": HBM_PEAK_GBS,
+                     "unit": "GB/s", "frac": b_alg_loc * n_v / ((k_ms + p2_ms) * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                     "cell_kernel_achieved": achieved, "cell_kernel_frac": achieved / HBM_PEAK_GBS,
+                     "step_frac": b_alg_loc / (1e-3 * (1e3 * t / args.steps)) / 1e9 / HBM_PEAK_GBS,
+                     "traffic": traffic, "traffic_step": traffic_step, "traffic_source": traffic_source,
                      "kernel": op.kernel_name(), "launches": launches,
                      "avg_launch_us": 1e3 * k_ms / max(launches, 1),
                      "alg_bytes_per_launch": b_alg_loc / stats["n_launches"],
-                     "kernel_ms_per_vmult": k_ms / max(n_v, 1)},
+                     "kernel_ms_per_vmult": k_ms / max(n_v, 1), "pass2_ms_per_vmult": p2_ms / max(n_v, 1)},
     }
     if rank == 0 and world == 1 and not args.no_cpu and not args.adaptive and not general and not args.renumber:
         cb, n_cpu, y_cpu = cpu_baseline(args)
         out["cpu_baseline"] = cb
         if n_cpu == n_glob and not args.float:
-            # GPU path vs the CPU path on the same mesh, one apply to the vector of 0.1s (north_star: "matching the
-            # reference CPU path ... to a stated floating-point tolerance": 1e-12 relative l2 in double)
-            src.fill_(0.1)
+            # GPU path vs the CPU path on the same mesh, one apply to the same seeded random vector (north_star:
+            # "matching the reference CPU path ... to a stated floating-point tolerance": 1e-12 relative l2 in double)
+            src.copy_(torch.from_numpy(parity_vector(N_loc)))
             op.vmult(dst, src, stream)
             torch.cuda.synchronize()
             y_gpu = dst.cpu().numpy()

@@ -75,6 +75,9 @@ struct mfgpu_handle {
   size_t ev_used = 0;
   double prof_ms = 0.0;
   uint64_t prof_vmults = 0;
+  std::vector<hipEvent_t> ev2;  // start/stop pairs around pass 2 (mfgpu_vmult / mfgpu_vmult_add only)
+  size_t ev2_used = 0;
+  double prof2_ms = 0.0;
 };
 
 namespace {
@@ -582,8 +585,23 @@ int vmult_main(mfgpu_handle *h, void *dst, const void *src, hipStream_t st, int 
 template <typename T>
 int vmult_typed(mfgpu_handle *h, void *dst, const void *src, hipStream_t st, int add) {
   int rc = vmult_main<T>(h, dst, src, st, add);
-  if (!rc) rc = vmult_pass2<T>(h, 0, dst, src, st, add);
+  if (rc) return rc;
+  if (h->prof && h->twopass) {
+    if (h->ev2_used + 2 > h->ev2.size()) {
+      hipEvent_t e0, e1;
+      HIP_TRY(hipEventCreate(&e0));
+      HIP_TRY(hipEventCreate(&e1));
+      h->ev2.push_back(e0);
+      h->ev2.push_back(e1);
+    }
+    HIP_TRY(hipEventRecord(h->ev2[h->ev2_used], st));
+  }
+  rc = vmult_pass2<T>(h, 0, dst, src, st, add);
   if (!rc) rc = vmult_pass2<T>(h, 1, dst, src, st, add);
+  if (!rc && h->prof && h->twopass) {
+    HIP_TRY(hipEventRecord(h->ev2[h->ev2_used + 1], st));
+    h->ev2_used += 2;
+  }
   return rc;
 }
 
@@ -775,6 +793,7 @@ void mfgpu_destroy(mfgpu_handle *h) {
   hipFree(h->d_halo);
   hipFree(h->d_stamps);
   for (hipEvent_t e : h->ev) hipEventDestroy(e);
+  for (hipEvent_t e : h->ev2) hipEventDestroy(e);
   delete h;
 }
 
@@ -839,6 +858,21 @@ int mfgpu_profile_enable(mfgpu_handle *h, int on) {
   h->ev_used = 0;
   h->prof_ms = 0.0;
   h->prof_vmults = 0;
+  h->ev2_used = 0;
+  h->prof2_ms = 0.0;
+  return 0;
+}
+
+int mfgpu_profile_read_pass2(mfgpu_handle *h, double *ms) {
+  if (!h || !ms) return MFGPU_EINVAL;
+  HIP_TRY(hipDeviceSynchronize());
+  for (size_t i = 0; i + 1 < h->ev2_used; i += 2) {
+    float t = 0.f;
+    HIP_TRY(hipEventElapsedTime(&t, h->ev2[i], h->ev2[i + 1]));
+    h->prof2_ms += t;
+  }
+  h->ev2_used = 0;
+  *ms = h->prof2_ms;
   return 0;
 }
 

@@ -43,7 +43,7 @@ SYMBOLS = [
     "mfgpu_create", "mfgpu_vmult", "mfgpu_vmult_add", "mfgpu_n_dofs", "mfgpu_memory_consumption",
     "mfgpu_destroy", "mfgpu_last_error", "mfgpu_plan_stats", "mfgpu_kernel_name", "mfgpu_compute_inverse_diagonal", "mfgpu_set_constrained_values",
     "mfgpu_vec_sadd", "mfgpu_vec_equ", "mfgpu_vec_scale", "mfgpu_vec_divide", "mfgpu_vec_invert", "mfgpu_vec_mul",
-    "mfgpu_vec_dot", "mfgpu_vec_l2_norm", "mfgpu_vec_add_and_dot", "mfgpu_vec_all_zero", "mfgpu_profile_enable", "mfgpu_profile_read",
+    "mfgpu_vec_dot", "mfgpu_vec_l2_norm", "mfgpu_vec_add_and_dot", "mfgpu_vec_all_zero", "mfgpu_profile_enable", "mfgpu_profile_read", "mfgpu_profile_read_pass2",
     "mfgpu_plan_create", "mfgpu_plan_destroy", "mfgpu_plan_array_u32", "mfgpu_plan_lmap", "mfgpu_plan_bflags",
     "mfgpu_vec_alloc", "mfgpu_vec_free", "mfgpu_vec_fill", "mfgpu_vec_from_host", "mfgpu_vec_to_host",
     "mfgpu_device_synchronize", "mfgpu_device_memory_info", "mfgpu_mesh_create_uniform", "mfgpu_mesh_create_adaptive", "mfgpu_mesh_create_ball", "mfgpu_mesh_create_from_leaves",
@@ -99,6 +99,7 @@ def lib():
         L.mfgpu_vec_all_zero.argtypes = [vp, z, i, vp, C.POINTER(i)]
         L.mfgpu_profile_enable.argtypes = [C.c_void_p, C.c_int]
         L.mfgpu_profile_read.argtypes = [C.c_void_p, C.POINTER(C.c_double), C.POINTER(C.c_uint64)]
+        L.mfgpu_profile_read_pass2.argtypes = [C.c_void_p, C.POINTER(C.c_double)]
         L.mfgpu_plan_create.argtypes = [C.POINTER(Desc), C.POINTER(C.c_void_p)]
         L.mfgpu_plan_destroy.argtypes = [C.c_void_p]
         L.mfgpu_plan_destroy.restype = None
@@ -540,6 +541,11 @@ class Operator:
         ms, nv = C.c_double(), C.c_uint64()
         _check(lib().mfgpu_profile_read(self._h, C.byref(ms), C.byref(nv)))
         return ms.value, int(nv.value)
+
+    def profile_read_pass2(self):
+        ms = C.c_double()
+        _check(lib().mfgpu_profile_read_pass2(self._h, C.byref(ms)))
+        return ms.value
 
 
 class MgHierarchy:

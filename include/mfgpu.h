@@ -148,6 +148,8 @@ const char *mfgpu_kernel_name(const mfgpu_handle *h);
  * with hipEvents on the launch stream when profiling is enabled (bench.py roofline leg).       */
 int mfgpu_profile_enable(mfgpu_handle *h, int on);
 int mfgpu_profile_read(mfgpu_handle *h, double *kernel_ms_total, uint64_t *n_vmults);
+/* ... and of the pass-2 kernels (reduce_classes) of the same mfgpu_vmult / mfgpu_vmult_add calls: 0 in coloured mode. */
+int mfgpu_profile_read_pass2(mfgpu_handle *h, double *pass2_ms_total);
 
 /* ---- host-only plan (no GPU needed): same planner the handle uses -------------------------
  * Lets CPU tests check the batching / colouring / first-touch logic.                         */

@@ -20,6 +20,12 @@ out = {"workload": workload, "kernel": name, "hbm_bytes_per_launch": v["hbm_byte
        "source": "rocprofv3 --pmc, separate passes for FETCH_SIZE, WRITE_SIZE "
                  "and TCC_EA0_RDREQ by size; reads = 128-B requests x 128 = 2 x FETCH_SIZE on gfx950; "
                  "tools/profile_bench.sh, tools/profile_summary.py)"}
+# all kernels of a vmult (cell loop launches + pass 2): the library's kernels launched at least as often as the
+# dominant one (setup kernels run once), per vmult = per launch of the dominant kernel
+per_vmult = {k: w["hbm_bytes"] * w["launches"] / v["launches"] for k, w in t["kernels"].items()
+             if k.startswith("mfgpu::") and w["launches"] >= v["launches"]}
+out["step_hbm_bytes_per_vmult"] = sum(per_vmult.values())
+out["step_kernels"] = per_vmult
 root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 hsh = hashlib.sha256()
 for f in sorted(glob.glob(os.path.join(root, "dealii-cuda_amd", "csrc", "*")) + [os.path.join(root, "include", "mfgpu.h")]):
