@@ -7,11 +7,13 @@
 // kernels of ConstraintHandlerGpu (save / zero / copy_edge_values / load).  Here the operator fuses its constrained
 // rows into the cell loop, so a level holds two operators over the same level mesh:
 //   A  : constrained rows = the level's Dirichlet dofs AND its refinement-edge dofs (what vmult / the smoother see)
-//   Ab : constrained rows = the Dirichlet dofs only (built only if the level has edge dofs)
-// and the interface matrices are compositions (K = the unconstrained level operator, C = Dirichlet + edge, E = edge):
-//   down: dst = 0 except dst[E] = (K (src with C zeroed))[E]   = (Ab x)[E],  x = src with C zeroed   (:306-330)
-//   up  : dst = K (src restricted to E), then dst[C] = 0       = Ab x, x = 0 except x[E] = src[E]     (:332-352)
-// (Ab's Dirichlet rows are identity rows acting on zeros in both cases.)
+//   Ab : K itself, NO constrained rows -- the reference's cell loop runs on a structure without constraints (:174-176)
+//        (built only if the level has edge dofs)
+// and the interface matrices are compositions (C = Dirichlet + edge, E = edge):
+//   down: dst = 0 except dst[E] = (K (src with C zeroed))[E]                                          (:306-330)
+//   up  : dst = K (src restricted to E), then dst[C] = 0                                              (:332-352)
+// An edge dof may also be a Dirichlet dof (a refinement edge that reaches the domain boundary): down then returns
+// (K x)[E] on it and up includes src[E] there, as the reference does; identity rows in Ab would lose both.
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
@@ -63,7 +65,7 @@ int interface_typed(mfgpu_level *L, bool down, T *dst, const T *src, hipStream_t
     return 0;
   }
   if (down) {
-    // x = src with C zeroed (constraint_handler.save_constrained_values, :315); y = Ab x; dst = 0, dst[E] = y[E]
+    // x = src with C zeroed (constraint_handler.save_constrained_values, :315); y = K x; dst = 0, dst[E] = y[E]
     if (hipMemcpyAsync(x, src, bytes, hipMemcpyDeviceToDevice, st) != hipSuccess) return MFGPU_EHIP;
     hipLaunchKernelGGL(set_indexed_kernel<T>, dim3(gc), dim3(256), 0, st, x, L->d_c, L->n_c, T(0));
     int rc = mfgpu_vmult(L->Ab, y, x, st);
@@ -71,7 +73,7 @@ int interface_typed(mfgpu_level *L, bool down, T *dst, const T *src, hipStream_t
     if (hipMemsetAsync(dst, 0, bytes, st) != hipSuccess) return MFGPU_EHIP;
     hipLaunchKernelGGL(copy_indexed_kernel<T>, dim3(ge), dim3(256), 0, st, dst, (const T *)y, L->d_e, L->n_e);
   } else {
-    // x = 0 except the edge values of src (copy_edge_values, :343); dst = Ab x; dst[C] = 0 (:351)
+    // x = 0 except the edge values of src (copy_edge_values, :343); dst = K x; dst[C] = 0 (:351)
     if (hipMemsetAsync(x, 0, bytes, st) != hipSuccess) return MFGPU_EHIP;
     hipLaunchKernelGGL(copy_indexed_kernel<T>, dim3(ge), dim3(256), 0, st, x, src, L->d_e, L->n_e);
     int rc = mfgpu_vmult(L->Ab, dst, x, st);
@@ -121,7 +123,10 @@ int mfgpu_level_create(const mfgpu_desc *desc, const uint32_t *edge_dofs, uint32
   int rc = mfgpu_create(&da, &L->A);
   if (rc) return fail(rc);
   if (L->n_e) {
-    if ((rc = mfgpu_create(desc, &L->Ab))) return fail(rc);
+    mfgpu_desc db = *desc;
+    db.constrained_dofs = nullptr;
+    db.n_constrained = 0;
+    if ((rc = mfgpu_create(&db, &L->Ab))) return fail(rc);
     const size_t es = desc->number_type == MFGPU_F64 ? 8 : 4;
     if (hipMalloc((void **)&L->d_c, c.size() * 4) != hipSuccess || hipMalloc((void **)&L->d_e, e.size() * 4) != hipSuccess ||
         hipMalloc(&L->tmp_x, (size_t)L->n_dofs * es) != hipSuccess || hipMalloc(&L->tmp_y, (size_t)L->n_dofs * es) != hipSuccess ||

@@ -24,11 +24,16 @@ def _edge_of_box(mesh, lo, hi):
 
 @pytest.mark.parametrize("dim,p,n,nt", [(2, 2, 8, mf.F64), (2, 4, 6, mf.F64), (3, 1, 6, mf.F64), (3, 2, 4, mf.F64), (3, 4, 4, mf.F64),
                                         (3, 4, 6, mf.F32), (3, 3, 4, mf.F64)])
-def test_level_operator_and_interface_matrices(dim, p, n, nt):
+@pytest.mark.parametrize("touch_boundary", [False, True])
+def test_level_operator_and_interface_matrices(dim, p, n, nt, touch_boundary):
     mesh = mf.Mesh.uniform(dim, p, n, number_type=nt)
     od = oracle_desc_from_mesh(mesh, dtype=np.float64)
     h = 2.0 / n
-    edge = _edge_of_box(mesh, -1.0 + h, -1.0 + h * (n // 2 + 1))
+    # touch_boundary: the box starts AT the domain boundary, so some edge dofs are Dirichlet dofs too (a refinement
+    # edge that reaches the boundary, as mfgpu_mg_hierarchy produces them)
+    edge = _edge_of_box(mesh, -1.0 + (0.0 if touch_boundary else h), -1.0 + h * (n // 2 + 1))
+    if touch_boundary:
+        assert len(np.intersect1d(edge, od.constrained)) > 0
     assert 0 < len(edge) < mesh.n_dofs
     lev = mf.Level(mesh.desc, edge, mesh)
     rng = np.random.default_rng(dim * 10 + p)
