@@ -137,7 +137,7 @@ def main():
                          "the C-ABI (mfgpu_vmult_dist: RCCL send/recv on a side stream, overlapped with pass 2); the "
                          "others: the Python test double pymfgpu/parallel.py over torch.distributed")
     ap.add_argument("--no-cpu", action="store_true")
-    ap.add_argument("--kernel", default="auto", choices=["auto", "pencils", "pencils_x", "planes"],
+    ap.add_argument("--kernel", default="auto", choices=["auto", "pencils", "pencils_x", "planes", "planes_2w"],
                     help="mfgpu_desc.kernel: cell-loop kernel family (measurements; the default is the library's choice)")
     ap.add_argument("--segments", type=int, default=0,
                     help="mfgpu_desc.cell_loop_segments (0 = the library's choice, 1 = no overlap of pass 2 with the cell loop)")
@@ -160,7 +160,6 @@ def main():
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
         launch_ranks(args.gpus, sys.argv[1:])  # before any import that could touch the GPU
         return
-    _imports()
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
@@ -168,6 +167,7 @@ def main():
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
     if os.environ.get("MFGPU_BENCH_ECHO_RANK"):  # tests/test_bench_launcher.py
         print(f"[bench] rank {rank} of {world} started", file=sys.stderr, flush=True)
+    _imports()
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU (the HIP path has no CPU fallback)")
     torch.cuda.set_device(local_rank)
@@ -202,7 +202,7 @@ def main():
     mesh.desc.max_dofs_per_batch = args.batch_dofs
     mesh.desc.cell_loop_segments = args.segments
     mesh.desc.kernel = {"auto": mf.KERNEL_AUTO, "pencils": mf.KERNEL_PENCILS, "pencils_x": mf.KERNEL_PENCILS_X,
-                        "planes": mf.KERNEL_PLANES}[args.kernel]
+                        "planes": mf.KERNEL_PLANES, "planes_2w": mf.KERNEL_PLANES_2W}[args.kernel]
     if args.colored:
         mesh.desc.flags |= mf.COLORED_SCATTER
     if args.general_jacobian:

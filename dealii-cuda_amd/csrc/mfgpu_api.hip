@@ -68,7 +68,8 @@ struct mfgpu_handle {
   uint32_t max_grid_ph = 0;  // ... of apply_planes3<HN> (the plane batches of cells with a hanging-node mask)
   bool xk = false;        // 3D two-pass kernel for three workgroups per CU (apply_batches_x)
   bool gk = false;        // general-Jacobian kernel (apply_batches_g)
-  bool pk = false;        // plane-per-thread kernel (apply_planes3): 3D uniform-Jacobian default for p = 2..4
+  bool pk = false;        // plane-per-thread kernel: 3D uniform-Jacobian default for p = 4
+  bool qk = false;        // ... apply_planes4 (MFGPU_KERNEL_PLANES_2W) instead of apply_planes3
   // profiling
   bool prof = false;
   std::vector<hipEvent_t> ev;  // start/stop pairs
@@ -81,6 +82,10 @@ struct mfgpu_handle {
 };
 
 namespace {
+
+template <typename T>
+hipError_t planes_launch(mfgpu_handle *h, const ApplyArgs<T> &a, bool hn, uint32_t grid, hipStream_t st,
+                         bool configure_only, size_t *lds_out, int *occupancy);
 
 template <typename P>
 int dev_upload(P **dst, const void *src, size_t bytes, size_t &acct) {
@@ -332,11 +337,11 @@ int create_arrays(mfgpu_handle *h, const mfgpu_desc &d) {
     int per_cu = 0, dev = 0;
     hipDeviceProp_t prop;
     size_t lds_p = 0;
-    HIP_TRY(p_launch<T>(P.n, dummy, nullptr, nullptr, false, 0, nullptr, true, &lds_p, &per_cu));
+    HIP_TRY(planes_launch<T>(h, dummy, false, 0, nullptr, true, &lds_p, &per_cu));
     if (P.n_plain_plane_batches < P.n_plane_batches) {  // batches of masked cells: apply_planes3<HN>
       int per_cu_h = 0;
       size_t lds_h = 0;
-      HIP_TRY(p_launch<T>(P.n, dummy, nullptr, nullptr, true, 0, nullptr, true, &lds_h, &per_cu_h));
+      HIP_TRY(planes_launch<T>(h, dummy, true, 0, nullptr, true, &lds_h, &per_cu_h));
       hipDeviceProp_t prop_h;
       int dev_h = 0;
       HIP_TRY(hipGetDevice(&dev_h));
@@ -463,6 +468,15 @@ int vmult_pass2(mfgpu_handle *h, int phase, void *dst, const void *src, hipStrea
   return rc;
 }
 
+// the plane kernel of this handle
+template <typename T>
+hipError_t planes_launch(mfgpu_handle *h, const ApplyArgs<T> &a0, bool hn, uint32_t grid, hipStream_t st,
+                         bool configure_only, size_t *lds_out, int *occupancy) {
+  const ApplyArgs<T> &a = a0;
+  return h->qk ? q_launch<T>(h->plan.n, a, h->S.data(), h->Dt.data(), hn, grid, st, configure_only, lds_out, occupancy)
+               : p_launch<T>(h->plan.n, a, h->S.data(), h->Dt.data(), hn, grid, st, configure_only, lds_out, occupancy);
+}
+
 // batches [b0, b1) of one scatter pass, each with the kernel family that owns it
 template <typename T>
 int launch_cells(mfgpu_handle *h, ApplyArgs<T> a, uint32_t b0, uint32_t b1, hipStream_t st) {
@@ -473,16 +487,14 @@ int launch_cells(mfgpu_handle *h, ApplyArgs<T> a, uint32_t b0, uint32_t b1, hipS
     a.batch0 = b0;
     a.batch_end = b1 < nplain ? b1 : nplain;
     const uint32_t nbat = a.batch_end - a.batch0;
-    HIP_TRY(p_launch<T>(P.n, a, h->S.data(), h->Dt.data(), false, nbat < h->max_grid_p ? nbat : h->max_grid_p, st,
-                        false, nullptr, nullptr));
+    HIP_TRY(planes_launch<T>(h, a, false, nbat < h->max_grid_p ? nbat : h->max_grid_p, st, false, nullptr, nullptr));
     b0 = a.batch_end;
   }
   if (b0 < npl && b0 < b1) {  // plane batches of cells WITH a mask
     a.batch0 = b0;
     a.batch_end = b1 < npl ? b1 : npl;
     const uint32_t nbat = a.batch_end - a.batch0;
-    HIP_TRY(p_launch<T>(P.n, a, h->S.data(), h->Dt.data(), true, nbat < h->max_grid_ph ? nbat : h->max_grid_ph, st,
-                        false, nullptr, nullptr));
+    HIP_TRY(planes_launch<T>(h, a, true, nbat < h->max_grid_ph ? nbat : h->max_grid_ph, st, false, nullptr, nullptr));
     b0 = a.batch_end;
   }
   if (b0 >= b1) return 0;
@@ -723,6 +735,7 @@ int mfgpu_create(const mfgpu_desc *desc, mfgpu_handle **out) {
   int rc = choose_kernel_and_plan(d, kc, h->plan);
   h->gk = kc.general;
   h->pk = kc.planes;
+  h->qk = d.kernel == MFGPU_KERNEL_PLANES_2W;
   h->xk = kc.pencils_x;
   if (rc) {
     delete h;
@@ -848,6 +861,7 @@ int mfgpu_plan_stats(const mfgpu_handle *h, uint64_t s[8]) {
 
 const char *mfgpu_kernel_name(const mfgpu_handle *h) {
   if (!h) return "";
+  if (h->pk && h->qk) return h->xk ? "apply_planes4+apply_batches_x" : "apply_planes4";
   return h->pk ? (h->xk ? "apply_planes3+apply_batches_x" : "apply_planes3")
                : h->gk ? (h->dim == 2 ? "apply_batches_g2" : "apply_batches_g") : h->xk ? "apply_batches_x" : "apply_batches";
 }

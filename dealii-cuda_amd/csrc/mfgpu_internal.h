@@ -34,6 +34,13 @@ constexpr int p_cell_stride(int n) {
   return s;
 }
 
+// apply_planes4 (mfgpu_kernels_q.hip): ONE transpose array, aliased with the batch array.  Element (x, y, z) of cell c
+// sits at c * q_cell_stride + x + n * y + q_plane_stride * z.  A thread of the xy-layout (lane = n c + z) accesses
+// c * SA + ZS * z + const, one of the yz-layout (lane = n c + x) c * SA + x + const: with SA = n and ZS = 1 (mod 32) both
+// are lane + const, i.e. distinct banks in every 32-lane group of a ds_read_b64 and every 16-lane group of a
+// ds_write_b64 (MI355X_MICROARCH.md, LDS table).  (p = 2: the smallest such strides are 99 / 33.)
+constexpr int q_plane_stride(int n) { return n == 5 ? 33 : n == 4 ? 17 : 33; }
+constexpr int q_cell_stride(int n) { return n * q_plane_stride(n); }
 // apply_planes3 on cells WITH a hanging-node mask: the constrained nodes of a cell get PRIVATE entries behind the
 // batch's dof list (p_priv_max(n) of them per batch), a copy of the gathered values, on which the 1D interpolation
 // passes of resolve_hanging_nodes (hanging_nodes.cuh:617-696) run line by line before the cell stages, and their
@@ -45,6 +52,19 @@ constexpr int p_priv_max(int n) { return n == 5 ? 384 : n == 4 ? 256 : 192; }
 // 16 bit each), then 2 rows with the counts (copies | x lines << 16; y lines | z lines << 16) in every lane
 constexpr int kHnOpRounds = 2;
 constexpr int p_hn_rows(int n) { return p_priv_max(n) / 64 + 3 * kHnOpRounds * 3 + 2; }
+
+// LDS of apply_planes4: max(transpose array incl. the idle lanes' scratch cell, batch array incl. private entries) --
+// aliased --, and behind it the hanging-node weight matrix
+template <typename T>
+constexpr size_t q_region_doubles(int n) {
+  const size_t t = ((size_t)(p_cells_per_wave(n) + 1) * q_cell_stride(n) * sizeof(T) + 7) / 8;
+  const size_t u = (size_t)p_kgu(n) * 64 + p_priv_max(n);
+  return t > u ? t : u;
+}
+template <typename T>
+constexpr size_t q_lds_bytes(int n, bool hn) {
+  return (q_region_doubles<T>(n) + (hn ? (size_t)n * n : 0)) * 8;
+}
 
 constexpr uint8_t kFlagConstrained = 1;  // batch dof is a constrained row (identity)
 constexpr uint8_t kFlagAdd = 2;          // batch is NOT the first toucher: dst += (else dst =)

@@ -71,6 +71,10 @@ hipError_t x_launch(int n, const ApplyArgs<T> &a, const double *S, const double 
 template <typename T>
 hipError_t p_launch(int n, const ApplyArgs<T> &a, const double *S, const double *Dt, bool hn, uint32_t grid,
                     hipStream_t st, bool configure_only, size_t *lds_out, int *occupancy);
+// ... two waves per SIMD (mfgpu_kernels_q.hip): same records, same arguments
+template <typename T>
+hipError_t q_launch(int n, const ApplyArgs<T> &a, const double *S, const double *Dt, bool hn, uint32_t grid,
+                    hipStream_t st, bool configure_only, size_t *lds_out, int *occupancy);
 template <typename T>
 hipError_t relayout_coef_launch(T *out, const T *in, const uint32_t *cell_batch, const uint32_t *cell_pos,
                                 size_t total, int n, hipStream_t st);

@@ -688,7 +688,7 @@ int build_plane_records(Plan &P, const uint32_t *constraint_mask) {
 int choose_kernel_and_plan(const mfgpu_desc &d, KernelChoice &kc, Plan &plan) {
   const bool general = !(d.flags & MFGPU_UNIFORM_J0), hn = (d.flags & MFGPU_HANGING_NODES) != 0;
   const bool colored = (d.flags & MFGPU_COLORED_SCATTER) != 0;
-  if (d.kernel > MFGPU_KERNEL_PLANES) {
+  if (d.kernel > MFGPU_KERNEL_PLANES_2W) {
     set_error("unknown mfgpu_desc.kernel");
     return MFGPU_EINVAL;
   }
@@ -696,7 +696,8 @@ int choose_kernel_and_plan(const mfgpu_desc &d, KernelChoice &kc, Plan &plan) {
   const bool pk_ok = d.dim == 3 && !general && !colored && d.degree >= 2 && d.degree <= 4 &&
                      d.n_dofs < (1u << 29);  // (vectors are addressed base + 32-bit byte offset)
   const bool xk_ok = d.dim == 3 && !general && !colored;
-  if ((d.kernel == MFGPU_KERNEL_PLANES && !pk_ok) || (d.kernel == MFGPU_KERNEL_PENCILS_X && !xk_ok) ||
+  const bool want_planes = d.kernel == MFGPU_KERNEL_PLANES || d.kernel == MFGPU_KERNEL_PLANES_2W;
+  if ((want_planes && !pk_ok) || (d.kernel == MFGPU_KERNEL_PENCILS_X && !xk_ok) ||
       (d.kernel == MFGPU_KERNEL_PENCILS && general)) {
     set_error("mfgpu_desc.kernel: this kernel family does not cover the description (see include/mfgpu.h)");
     return MFGPU_EUNSUPPORTED;
@@ -704,7 +705,7 @@ int choose_kernel_and_plan(const mfgpu_desc &d, KernelChoice &kc, Plan &plan) {
   kc.general = general;
   // by default the plane kernel serves p = 4 only: at p = 2, 3 the pencil kernel measures faster
   // (on meshes with hanging nodes also p = 3: 0.174 instead of 0.256 ms on the bmop ADAPTIVE_GRID mesh, n_ref = 6)
-  kc.planes = pk_ok && (d.kernel == MFGPU_KERNEL_PLANES ||
+  kc.planes = pk_ok && (want_planes ||
                         (d.kernel == MFGPU_KERNEL_AUTO && (d.degree == 4 || (hn && d.degree == 3))));
   kc.pencils_x = xk_ok && !kc.planes && d.kernel != MFGPU_KERNEL_PENCILS;
   PlanLimits lim;

@@ -17,7 +17,7 @@ LIB_PATH = os.environ.get("MFGPU_LIB") or os.path.join(os.path.dirname(_HERE), "
 
 F64, F32 = 0, 1
 UNIFORM_J0, HANGING_NODES, COLORED_SCATTER = 1, 2, 1 << 8
-KERNEL_AUTO, KERNEL_PENCILS, KERNEL_PENCILS_X, KERNEL_PLANES = 0, 1, 2, 3  # Desc.kernel
+KERNEL_AUTO, KERNEL_PENCILS, KERNEL_PENCILS_X, KERNEL_PLANES, KERNEL_PLANES_2W = 0, 1, 2, 3, 4  # Desc.kernel
 
 
 class MfgpuError(RuntimeError):

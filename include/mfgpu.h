@@ -106,7 +106,10 @@ typedef struct mfgpu_desc {
 #define MFGPU_KERNEL_AUTO 0
 #define MFGPU_KERNEL_PENCILS 1   /* apply_batches: a thread owns a 1D pencil, 2 workgroups per CU (2D; coloured mode)   */
 #define MFGPU_KERNEL_PENCILS_X 2 /* apply_batches_x: the same for 3 workgroups per CU (3D two-pass; hanging nodes)      */
-#define MFGPU_KERNEL_PLANES 3    /* apply_planes3: a thread owns a 2D plane, one wave per batch (3D conforming, p = 2..4) */
+#define MFGPU_KERNEL_PLANES 3    /* apply_planes3: a thread owns a 2D plane, one wave per batch, one wave per SIMD (3D, p = 2..4) */
+#define MFGPU_KERNEL_PLANES_2W 4 /* apply_planes4: the same plan and records with half the resources per wave -- one LDS
+                                    transpose array aliased with the batch array, <= 256 registers -- for two waves per
+                                    SIMD; measures equal to apply_planes3 on MI355X (profiles/r03_notes.md), not the default */
 
 /* ---- operator (replaces LaplaceOperatorGpu::reinit / vmult / vmult_add / clear) -------- */
 

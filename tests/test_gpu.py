@@ -57,7 +57,7 @@ def test_vmult_matches_oracle(dim, p, n, nt, colored):
 
 
 KERNELS = [(mf.KERNEL_PENCILS, "apply_batches"), (mf.KERNEL_PENCILS_X, "apply_batches_x"),
-           (mf.KERNEL_PLANES, "apply_planes3")]
+           (mf.KERNEL_PLANES, "apply_planes3"), (mf.KERNEL_PLANES_2W, "apply_planes4")]
 
 
 @pytest.mark.parametrize("kern,name", KERNELS, ids=[k[1] for k in KERNELS])

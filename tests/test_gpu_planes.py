@@ -14,18 +14,24 @@ from util import desc_from_oracle, oracle_desc_from_mesh
 
 pytestmark = pytest.mark.gpu
 
+# the plane plan's two kernels: apply_planes3 (one wave per SIMD, the default) and apply_planes4 (same records, half the
+# LDS and registers per wave; mfgpu_desc.kernel = PLANES_2W)
+PLANE_KERNELS = [(mf.KERNEL_PLANES, "apply_planes3"), (mf.KERNEL_PLANES_2W, "apply_planes4")]
+PK = pytest.mark.parametrize("pk,pk_name", PLANE_KERNELS, ids=[k[1] for k in PLANE_KERNELS])
+
 # (p, cells per direction): meshes with several batches of the default size (64 / n cells), ragged remainders included
 SIZES = [(2, 5), (2, 9), (3, 4), (3, 7), (4, 3), (4, 5), (4, 7)]
 
 
 @pytest.mark.parametrize("p,n", SIZES)
 @pytest.mark.parametrize("nt", [mf.F64, mf.F32])
-def test_planes_vmult_and_add(p, n, nt):
+@PK
+def test_planes_vmult_and_add(p, n, nt, pk, pk_name):
     mesh = mf.Mesh.uniform(3, p, n, number_type=nt)
     od = oracle_desc_from_mesh(mesh, dtype=np.float64)
-    mesh.desc.kernel = mf.KERNEL_PLANES
+    mesh.desc.kernel = pk
     op = mf.Operator(mesh.desc, mesh)
-    assert op.kernel_name() == "apply_planes3"
+    assert op.kernel_name() == pk_name
     st = op.plan_stats()
     assert st["max_batch_cells"] <= 64 // (p + 1) and st["n_batches"] >= 2
     rng = np.random.default_rng(1000 * p + n)
@@ -38,13 +44,14 @@ def test_planes_vmult_and_add(p, n, nt):
 
 @pytest.mark.parametrize("p,n,cells", [(4, 4, 1), (4, 4, 2), (4, 4, 5), (4, 5, 7), (4, 6, 12), (3, 5, 3), (3, 6, 16),
                                        (2, 7, 4), (2, 8, 21)])
-def test_planes_batch_sizes(p, n, cells):
+@PK
+def test_planes_batch_sizes(p, n, cells, pk, pk_name):
     """batches of 1 .. 64/n cells (partly filled waves, idle lanes) give the same operator"""
     od = o.uniform_mesh_desc(3, p, n, coefficient=lambda x: 1.0 + x[..., 0] ** 2 + 0.5 * np.sin(3 * x[..., 1]) + x[..., 2])
     x = np.random.default_rng(p * 100 + n * 10 + cells).standard_normal(od.n_dofs)
-    desc, keep = desc_from_oracle(od, max_cells_per_batch=cells, kernel=mf.KERNEL_PLANES)
+    desc, keep = desc_from_oracle(od, max_cells_per_batch=cells, kernel=pk)
     op = mf.Operator(desc, keep)
-    assert op.kernel_name() == "apply_planes3"
+    assert op.kernel_name() == pk_name
     assert op.plan_stats()["max_batch_cells"] <= cells
     assert rel(gpu_vmult(op, x), o.vmult(od, x)) <= 1e-12
 
@@ -96,6 +103,9 @@ def test_planes_unsupported_requests_fail_loudly():
 @pytest.mark.parametrize("p,n,wgs,kern,nt", [(4, 6, 1, mf.KERNEL_PLANES, mf.F64), (4, 7, 3, mf.KERNEL_PLANES, mf.F64),
                                              (4, 9, 5, mf.KERNEL_PLANES, mf.F32), (4, 12, 9, mf.KERNEL_PLANES, mf.F64),
                                              (3, 8, 3, mf.KERNEL_PLANES, mf.F64), (2, 9, 2, mf.KERNEL_PLANES, mf.F64),
+                                             (4, 6, 1, mf.KERNEL_PLANES_2W, mf.F64), (4, 7, 3, mf.KERNEL_PLANES_2W, mf.F64),
+                                             (4, 9, 5, mf.KERNEL_PLANES_2W, mf.F32), (3, 8, 3, mf.KERNEL_PLANES_2W, mf.F64),
+                                             (2, 9, 2, mf.KERNEL_PLANES_2W, mf.F64),
                                              (4, 6, 2, mf.KERNEL_PENCILS_X, mf.F64), (2, 9, 3, mf.KERNEL_PENCILS_X, mf.F64),
                                              (6, 3, 1, mf.KERNEL_AUTO, mf.F64), (4, 5, 3, mf.KERNEL_PENCILS, mf.F64)])
 def test_few_workgroups_walk_many_batches(p, n, wgs, kern, nt):
@@ -156,7 +166,8 @@ def _all_masks3():
 
 @pytest.mark.parametrize("p,n,wgs,nt", [(4, 5, 0, mf.F64), (4, 6, 2, mf.F64), (4, 5, 3, mf.F32), (3, 5, 0, mf.F64), (3, 6, 2, mf.F64),
                                         (2, 6, 0, mf.F64), (2, 7, 3, mf.F64)])
-def test_planes_hanging_node_batches_synthetic_masks(p, n, wgs, nt):
+@PK
+def test_planes_hanging_node_batches_synthetic_masks(p, n, wgs, nt, pk, pk_name):
     """apply_planes3<HN>: every mask of the reference's known-answer test (type x face bits, edge masks) on cells of a
     conforming mesh -- private entries, interpolation passes x, y, z before the cell stages and the transposed passes
     after them -- for every degree the plane kernel serves, few workgroups (several batches per workgroup) included;
@@ -170,22 +181,23 @@ def test_planes_hanging_node_batches_synthetic_masks(p, n, wgs, nt):
     od.constraint_mask = cm
     x, y0 = rng.standard_normal(od.n_dofs), rng.standard_normal(od.n_dofs)
     xt, y0t = (v.astype(mf.np_dtype(nt)).astype(np.float64) for v in (x, y0))
-    desc, keep = desc_from_oracle(od, number_type=nt, kernel=mf.KERNEL_PLANES, max_workgroups=wgs)
+    desc, keep = desc_from_oracle(od, number_type=nt, kernel=pk, max_workgroups=wgs)
     op = mf.Operator(desc, keep)
-    assert op.kernel_name() == "apply_planes3"
+    assert op.kernel_name() == pk_name
     assert rel(gpu_vmult(op, x, nt), o.vmult(od, xt)) <= TOL[nt]
     assert rel(gpu_vmult(op, x, nt, y0=y0), o.vmult_add(od, y0t, xt)) <= TOL[nt]
 
 
 @pytest.mark.parametrize("p,nref", [(4, 4), (4, 5), (3, 4), (2, 5)])
-def test_planes_adaptive_mesh_and_inverse_diagonal(p, nref):
+@PK
+def test_planes_adaptive_mesh_and_inverse_diagonal(p, nref, pk, pk_name):
     """bmop -DADAPTIVE_GRID mesh entirely in the plane kernel (cells with a mask in batches of their own); the inverse
     diagonal runs on the same plan"""
     mesh = mf.Mesh.adaptive(3, p, nref)
     od = oracle_desc_from_mesh(mesh)
-    mesh.desc.kernel = mf.KERNEL_PLANES
+    mesh.desc.kernel = pk
     op = mf.Operator(mesh.desc, mesh)
-    assert op.kernel_name() == "apply_planes3"
+    assert op.kernel_name() == pk_name
     rng = np.random.default_rng(p + nref)
     x, y0 = rng.standard_normal(mesh.n_dofs), rng.standard_normal(mesh.n_dofs)
     assert rel(gpu_vmult(op, x), o.vmult(od, x)) <= 1e-12
