@@ -513,7 +513,7 @@ int launch_cells(mfgpu_handle *h, ApplyArgs<T> a, uint32_t b0, uint32_t b1, hipS
 }
 
 template <typename T>
-int vmult_main(mfgpu_handle *h, void *dst, const void *src, hipStream_t st, int add) {
+ApplyArgs<T> make_args(mfgpu_handle *h, void *dst, const void *src, int add) {
   const Plan &P = h->plan;
   ApplyArgs<T> a;
   a.batch_cell_off = h->d_batch_cell_off;
@@ -542,9 +542,13 @@ int vmult_main(mfgpu_handle *h, void *dst, const void *src, hipStream_t st, int 
   a.add = add;
   a.stamps = h->d_stamps;
   a.dbg = 0;
-#ifdef MFGPU_STAMPS
-  if (const char *e = getenv("MFGPU_DBG")) a.dbg = atoi(e);
-#endif
+  return a;
+}
+
+template <typename T>
+int vmult_main(mfgpu_handle *h, void *dst, const void *src, hipStream_t st, int add) {
+  const Plan &P = h->plan;
+  ApplyArgs<T> a = make_args<T>(h, dst, src, add);
   if (h->prof) {
     if (h->ev_used + 2 > h->ev.size()) {
       hipEvent_t e0, e1;
@@ -694,6 +698,40 @@ namespace mfgpu {
 int handle_number_type(const mfgpu_handle *h) { return h->number_type; }
 int handle_set_priority_dofs(mfgpu_handle *h, const uint32_t *ids, uint32_t n) {
   return h->twopass ? upload_pass2(h, ids, n) : 0;
+}
+int handle_n_batches(const mfgpu_handle *h) { return (int)h->plan.batch_cell_off.size() - 1; }
+bool handle_ranged_ok(const mfgpu_handle *h) { return h->twopass && h->seg_end.size() == 1; }
+int handle_batches_touching(const mfgpu_handle *h, const uint32_t *ids, uint32_t n, std::vector<uint8_t> &flags) {
+  const Plan &P = h->plan;
+  std::vector<uint8_t> mark(P.n_dofs, 0);
+  for (uint32_t i = 0; i < n; ++i) {
+    if (ids[i] >= P.n_dofs) {
+      set_error("interface dof out of range");
+      return MFGPU_EINVAL;
+    }
+    mark[ids[i]] = 1;
+  }
+  const size_t nb = P.batch_cell_off.size() - 1;
+  flags.assign(nb, 0);
+  for (size_t b = 0; b < nb; ++b)
+    for (uint32_t t = P.batch_dof_off[b]; t < P.batch_dof_off[b + 1]; ++t)
+      if (mark[P.bdofs[t] & 0x7fffffffu]) {
+        flags[b] = 1;
+        break;
+      }
+  return 0;
+}
+int handle_cells_range(mfgpu_handle *h, uint32_t b0, uint32_t b1, void *dst, const void *src, void *stream, int add) {
+  if (b0 >= b1) return 0;
+  hipStream_t st = (hipStream_t)stream;
+  if (h->number_type == MFGPU_F64) return launch_cells<double>(h, make_args<double>(h, dst, src, add), b0, b1, st);
+  return launch_cells<float>(h, make_args<float>(h, dst, src, add), b0, b1, st);
+}
+int handle_pass2_group(mfgpu_handle *h, int group, void *dst, const void *src, void *stream, int add) {
+  if (!h->twopass) return 0;
+  hipStream_t st = (hipStream_t)stream;
+  return h->number_type == MFGPU_F64 ? launch_pass2_group<double>(h, (size_t)group, dst, src, st, add)
+                                     : launch_pass2_group<float>(h, (size_t)group, dst, src, st, add);
 }
 int handle_vmult_phase(mfgpu_handle *h, int phase, void *dst, const void *src, void *stream, int add) {
   hipStream_t st = (hipStream_t)stream;

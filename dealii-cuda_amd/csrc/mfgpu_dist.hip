@@ -3,13 +3,20 @@
 // local cell loop.  The reference is single-GPU (no MPI / NCCL anywhere); this is new work
 // shaped by SURVEY.md 8e:
 //
-//   mfgpu_vmult_dist_begin   cell loop of the slab            (launch stream)
-//                            pass 2 of the INTERFACE dofs     (launch stream)   -> the planes hold the slab's sums
-//                            pack the planes                  (launch stream), event
-//                            grouped ncclSend / ncclRecv with both neighbours  (side stream, after the event)
-//                            pass 2 of all other dofs         (launch stream)   -- overlaps the exchange
+//   mfgpu_vmult_dist_begin   cell loop over the batches that touch an interface plane   (launch stream), event
+//                            pass 2 of the INTERFACE dofs, pack the planes,            (side stream, behind the event)
+//                            grouped ncclSend / ncclRecv with both neighbours          (side stream)
+//                            cell loop over the interior batches, pass 2 of the rest   (launch stream) -- overlap the
+//                                                                                        whole exchange
 //   mfgpu_vmult_dist_end     wait for the exchange; dst[plane] += received, constrained rows excepted (identity
 //                            rows on both sides, laplace_operator_gpu.h:300-302)
+//
+// (cells touching an interface first, exchange, interior cells overlap the exchange.)  The
+// interface batches are found from the plan at attach time: the batches listing an interface dof lie, in plan order,
+// at the two ends of the slab's batch sequence (the planner keeps the caller's z-major cell order); the longest run
+// of batches that touch no interface dof is the interior.  If the interface batches are more than 60 % of the slab
+// (thin slabs), or the operator runs its cell loop in several segments or in coloured mode, the round-2 schedule is
+// used instead: whole cell loop, pass 2 of the interface dofs, pack, exchange next to pass 2 of the rest.
 //
 // A slab shares dofs only with its two neighbours, so the exchange is two point-to-point transfers per rank, not a
 // collective over all ranks.  Transports: RCCL (ncclSend / ncclRecv on a communicator created from a unique id), or
@@ -53,8 +60,12 @@ struct mfgpu_dist {
   uint8_t *d_free[2] = {};              // 1: summed with the neighbour, 0: constrained (identity row)
   void *d_send[2] = {}, *d_recv[2] = {};
   hipStream_t side = nullptr;
-  hipEvent_t ev_packed = nullptr, ev_done = nullptr;
+  hipEvent_t ev_packed = nullptr, ev_done = nullptr, ev_if = nullptr;
   bool in_flight = false;
+  // interface-first schedule (set by mfgpu_dist_attach): batches [0, r1_end) and [r2_begin, n_batches) touch an
+  // interface plane, [r1_end, r2_begin) is the interior
+  bool interface_first = false;
+  uint32_t r1_end = 0, r2_begin = 0, n_batches = 0;
 };
 
 namespace {
@@ -86,12 +97,13 @@ int pack_planes(mfgpu_dist *d, const void *vec, hipStream_t st) {
   return 0;
 }
 
-// grouped send / recv with both neighbours on the side stream, behind the pack
+// grouped send / recv with both neighbours on the side stream, behind the pack (which ran on `st`: the launch stream,
+// or the side stream itself)
 int start_exchange(mfgpu_dist *d, hipStream_t st) {
   HIP_TRY(hipEventRecord(d->ev_packed, st));
   d->in_flight = true;
   if (!d->comm) return 0;  // in-process transport: the copies happen in finish_exchange, when every peer has packed
-  HIP_TRY(hipStreamWaitEvent(d->side, d->ev_packed, 0));
+  if (st != d->side) HIP_TRY(hipStreamWaitEvent(d->side, d->ev_packed, 0));
   const ncclDataType_t dt = d->number_type == MFGPU_F64 ? ncclDouble : ncclFloat;
   NCCL_TRY(ncclGroupStart());
   for (int w = 0; w < 2; ++w) {
@@ -114,6 +126,7 @@ int finish_exchange(mfgpu_dist *d, void *vec, hipStream_t st) {
   if (d->comm) {
     HIP_TRY(hipStreamWaitEvent(st, d->ev_done, 0));
   } else {
+    HIP_TRY(hipStreamWaitEvent(st, d->ev_packed, 0));  // this slab's own planes are complete (side stream)
     for (int w = 0; w < 2; ++w) {
       if (!d->n_if[w]) continue;
       mfgpu_dist *p = d->local_peer[w];
@@ -200,9 +213,14 @@ int mfgpu_dist_create(const void *id128, int rank, int world, const uint32_t *lo
       return fail(MFGPU_ENOMEM);
     }
   }
-  if (hipStreamCreateWithFlags(&d->side, hipStreamNonBlocking) != hipSuccess ||
+  // highest priority: the exchange's short kernels (pass 2 of the planes, pack, RCCL's send / recv) should get wave
+  // slots ahead of the interior cell loop that runs beside them
+  int prio_least = 0, prio_greatest = 0;
+  if (hipDeviceGetStreamPriorityRange(&prio_least, &prio_greatest) != hipSuccess) prio_greatest = 0;
+  if (hipStreamCreateWithPriority(&d->side, hipStreamNonBlocking, prio_greatest) != hipSuccess ||
       hipEventCreateWithFlags(&d->ev_packed, hipEventDisableTiming) != hipSuccess ||
-      hipEventCreateWithFlags(&d->ev_done, hipEventDisableTiming) != hipSuccess) {
+      hipEventCreateWithFlags(&d->ev_done, hipEventDisableTiming) != hipSuccess ||
+      hipEventCreateWithFlags(&d->ev_if, hipEventDisableTiming) != hipSuccess) {
     set_error("mfgpu_dist_create: stream / event creation failed");
     return fail(MFGPU_EHIP);
   }
@@ -238,7 +256,38 @@ int mfgpu_dist_attach(mfgpu_dist *d, mfgpu_handle *h) {
   }
   std::vector<uint32_t> all(d->ids[0]);
   all.insert(all.end(), d->ids[1].begin(), d->ids[1].end());
-  return handle_set_priority_dofs(h, all.data(), (uint32_t)all.size());
+  int rc = handle_set_priority_dofs(h, all.data(), (uint32_t)all.size());
+  if (rc) return rc;
+  // interface-first schedule: the longest run of batches that touch no interface dof is the interior
+  d->interface_first = false;
+  d->n_batches = (uint32_t)handle_n_batches(h);
+  if (all.empty() || !handle_ranged_ok(h) || d->n_batches < 3) return 0;
+  std::vector<uint8_t> touch;
+  if ((rc = handle_batches_touching(h, all.data(), (uint32_t)all.size(), touch))) return rc;
+  uint32_t best_lo = 0, best_len = 0, run_lo = 0;
+  for (uint32_t b = 0; b <= d->n_batches; ++b)
+    if (b == d->n_batches || touch[b]) {
+      if (b - run_lo > best_len) {
+        best_len = b - run_lo;
+        best_lo = run_lo;
+      }
+      run_lo = b + 1;
+    }
+  if ((uint64_t)best_len * 10 >= (uint64_t)d->n_batches * 4) {  // interior >= 40 % of the slab's batches
+    d->interface_first = true;
+    d->r1_end = best_lo;
+    d->r2_begin = best_lo + best_len;
+  }
+  return 0;
+}
+
+int mfgpu_dist_schedule(const mfgpu_dist *d, uint32_t info[4]) {
+  if (!d || !info) return MFGPU_EINVAL;
+  info[0] = d->interface_first ? 1u : 0u;
+  info[1] = d->r1_end;
+  info[2] = d->r2_begin;
+  info[3] = d->n_batches;
+  return 0;
 }
 
 int mfgpu_vmult_dist_begin(mfgpu_handle *h, mfgpu_dist *d, void *dst, const void *src, void *stream) {
@@ -247,6 +296,21 @@ int mfgpu_vmult_dist_begin(mfgpu_handle *h, mfgpu_dist *d, void *dst, const void
     return MFGPU_EINVAL;
   }
   hipStream_t st = (hipStream_t)stream;
+  if (d->interface_first && (uint32_t)handle_n_batches(h) == d->n_batches) {
+    // SURVEY.md 8e steps 1-3.  The side stream writes dst on the interface planes only (pass 2 of the priority dofs);
+    // the interior batches and the rest of pass 2 write every other entry: no two streams touch the same entry.
+    int rc = handle_cells_range(h, 0, d->r1_end, dst, src, stream, 0);
+    if (!rc) rc = handle_cells_range(h, d->r2_begin, d->n_batches, dst, src, stream, 0);
+    if (rc) return rc;
+    HIP_TRY(hipEventRecord(d->ev_if, st));
+    HIP_TRY(hipStreamWaitEvent(d->side, d->ev_if, 0));
+    rc = handle_pass2_group(h, 0, dst, src, d->side, 0);  // the interface planes hold the slab's sums
+    if (!rc) rc = pack_planes(d, dst, d->side);
+    if (!rc) rc = start_exchange(d, d->side);
+    if (!rc) rc = handle_cells_range(h, d->r1_end, d->r2_begin, dst, src, stream, 0);  // overlaps the exchange
+    if (!rc) rc = handle_pass2_group(h, 1, dst, src, stream, 0);
+    return rc;
+  }
   int rc = handle_vmult_phase(h, 0, dst, src, stream, 0);
   if (!rc) rc = handle_vmult_phase(h, 1, dst, src, stream, 0);  // the interface planes are complete
   if (!rc) rc = pack_planes(d, dst, st);
@@ -264,6 +328,12 @@ int mfgpu_vmult_dist_end(mfgpu_handle *h, mfgpu_dist *d, void *dst, void *stream
 }
 
 int mfgpu_vmult_dist(mfgpu_handle *h, mfgpu_dist *d, void *dst, const void *src, void *stream) {
+  if (d && !d->comm && (d->n_if[0] || d->n_if[1])) {
+    // in-process transport: _end copies the neighbour's packed planes, which exist only once the neighbour's _begin
+    // has run -- begin ALL slabs, then end all of them (a wait on a never-recorded event is no wait)
+    set_error("mfgpu_vmult_dist on the in-process transport: call mfgpu_vmult_dist_begin for every slab, then _end");
+    return MFGPU_EINVAL;
+  }
   int rc = mfgpu_vmult_dist_begin(h, d, dst, src, stream);
   if (!rc) rc = mfgpu_vmult_dist_end(h, d, dst, stream);
   return rc;
@@ -282,6 +352,7 @@ void mfgpu_dist_destroy(mfgpu_dist *d) {
   if (d->side) hipStreamDestroy(d->side);
   if (d->ev_packed) hipEventDestroy(d->ev_packed);
   if (d->ev_done) hipEventDestroy(d->ev_done);
+  if (d->ev_if) hipEventDestroy(d->ev_if);
   delete d;
 }
 

@@ -159,6 +159,14 @@ int derive_tables(int n, const double *shape_values, const double *shape_gradien
 int handle_number_type(const mfgpu_handle *h);
 int handle_set_priority_dofs(mfgpu_handle *h, const uint32_t *ids, uint32_t n);
 int handle_vmult_phase(mfgpu_handle *h, int phase, void *dst, const void *src, void *stream, int add);
+// interface-first schedule of mfgpu_dist: the batches that list any of `ids` (flags[b] = 1),
+// the cell loop over a batch range, one pass-2 group (0 = the priority dofs, 1 = the rest) on a stream of the caller's
+// choice.  handle_ranged_ok: two-pass mode with one cell-loop segment (else the caller keeps the phase schedule).
+int handle_n_batches(const mfgpu_handle *h);
+bool handle_ranged_ok(const mfgpu_handle *h);
+int handle_batches_touching(const mfgpu_handle *h, const uint32_t *ids, uint32_t n, std::vector<uint8_t> &flags);
+int handle_cells_range(mfgpu_handle *h, uint32_t b0, uint32_t b1, void *dst, const void *src, void *stream, int add);
+int handle_pass2_group(mfgpu_handle *h, int group, void *dst, const void *src, void *stream, int add);
 
 }  // namespace mfgpu
 

@@ -49,7 +49,7 @@ SYMBOLS = [
     "mfgpu_device_synchronize", "mfgpu_device_memory_info", "mfgpu_mesh_create_uniform", "mfgpu_mesh_create_adaptive", "mfgpu_mesh_create_ball", "mfgpu_mesh_create_from_leaves",
     "mfgpu_mesh_cell_levels", "mfgpu_mesh_destroy",
     "mfgpu_mesh_desc", "mfgpu_mesh_dof_coords", "mfgpu_mesh_interface_dofs",
-    "mfgpu_dist_unique_id", "mfgpu_dist_create", "mfgpu_dist_connect_local", "mfgpu_dist_attach",
+    "mfgpu_dist_unique_id", "mfgpu_dist_create", "mfgpu_dist_connect_local", "mfgpu_dist_attach", "mfgpu_dist_schedule",
     "mfgpu_vmult_dist_begin", "mfgpu_vmult_dist_end", "mfgpu_vmult_dist", "mfgpu_dist_destroy",
     "mfgpu_transfer_create", "mfgpu_transfer_create_from_meshes", "mfgpu_transfer_prolongate",
     "mfgpu_transfer_restrict_and_add", "mfgpu_transfer_memory_consumption", "mfgpu_transfer_destroy",
@@ -721,6 +721,13 @@ class Dist:
 
     def attach(self, op: "Operator"):
         _check(lib().mfgpu_dist_attach(self._d, op._h))
+
+    def schedule(self):
+        """(interface_first, r1_end, r2_begin, n_batches): mfgpu_dist_schedule"""
+        info = (C.c_uint32 * 4)()
+        lib().mfgpu_dist_schedule.argtypes = [C.c_void_p, C.c_void_p]
+        _check(lib().mfgpu_dist_schedule(self._d, info))
+        return bool(info[0]), int(info[1]), int(info[2]), int(info[3])
 
     def vmult_begin(self, op, dst, src, stream=None):
         _check(lib().mfgpu_vmult_dist_begin(op._h, self._d, _ptr(dst), _ptr(src), stream))

@@ -233,6 +233,11 @@ int mfgpu_dist_create(const void *id128, int rank, int world, const uint32_t *lo
 int mfgpu_dist_connect_local(mfgpu_dist *lower_rank, mfgpu_dist *upper_rank);
 /* tells the operator which dofs the exchange needs first (re-orders its pass 2); once per (operator, dist) pair */
 int mfgpu_dist_attach(mfgpu_dist *d, mfgpu_handle *h);
+/* the schedule mfgpu_dist_attach chose: info[0] = 1: interface-first (the batches [0, info[1]) and
+ * [info[2], info[3]) touch an interface plane and run first, their pass 2, the pack and the exchange run on a side
+ * stream next to the interior batches [info[1], info[2]) and the rest of pass 2); 0: whole cell loop, then the exchange
+ * next to pass 2 of the non-interface dofs (thin slabs, segmented or coloured cell loops)                              */
+int mfgpu_dist_schedule(const mfgpu_dist *d, uint32_t info[4]);
 /* dst = A src on the slab, then the exchange.  _begin: cell loop, pass 2 of the interface dofs, start of the
  * transfers (side stream), pass 2 of the rest; _end: wait for the transfers, add.  mfgpu_vmult_dist = both (RCCL
  * transport or world == 1; with the in-process transport call _begin on every slab before any _end).             */

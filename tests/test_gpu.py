@@ -190,6 +190,29 @@ def test_errors_are_loud():
         mf.Operator(d2, mesh)
 
 
+@pytest.mark.parametrize("p,n,nt", [(4, 54, mf.F64), (6, 36, mf.F64), (4, 54, mf.F32)], ids=["C2_p4_n54", "C5_p6_n36", "C2_float"])
+def test_full_size_matches_cpu_twin(p, n, nt):
+    """BASELINE configs C2 (p = 4, n = 54: 10 218 313 dofs) and C5 (p = 6, n = 36) at FULL size against the CPU twin
+    oracle/cpu_ref.c (pinned to the numpy oracle by tests/test_cpu_ref.py; the restatement of
+    laplace_operator_cpu.cc:122-143, 178-211) on the same mesh and the same seeded random vector -- every cell
+    contributes, unlike the protocol's vector of 0.1s.  Tolerance: relative l2 <= 1e-12 (double), 1e-5 (float)."""
+    from oracle import cpu_ref
+    mesh = mf.Mesh.uniform(3, p, n, number_type=nt)
+    od = oracle_desc_from_mesh(mesh, dtype=np.float64)
+    ref = cpu_ref.CpuRef(od, cpu_ref.structured_cell_colors([n] * 3))
+    cpu_ref.set_threads(cpu_ref.cpu_share())
+    op = mf.Operator(mesh.desc, mesh)
+    rng = np.random.default_rng(p * 1000 + n)
+    x, y0 = rng.standard_normal(mesh.n_dofs), rng.standard_normal(mesh.n_dofs)
+    xt, y0t = (v.astype(mf.np_dtype(nt)).astype(np.float64) for v in (x, y0))
+    want = ref.vmult(xt)
+    assert rel(gpu_vmult(op, x, nt), want) <= TOL[nt]
+    assert rel(gpu_vmult(op, x, nt, y0=y0), want + y0t) <= TOL[nt]
+    if p == 4 and nt == mf.F64:  # the other plane kernel on the same inputs
+        mesh.desc.kernel = mf.KERNEL_PLANES_2W
+        assert rel(gpu_vmult(mf.Operator(mesh.desc, mesh), x, nt), want) <= TOL[nt]
+
+
 @pytest.mark.parametrize("n", [54])
 def test_full_size_properties(n):
     """BASELINE config C2 (p=4, 3D, n=54: 157 464 cells, 10 218 313 dofs): size-independent
@@ -446,9 +469,11 @@ def test_slab_decomposition_with_the_gpu_operator(p, n, world):
         x = acc
 
 
-@pytest.mark.parametrize("p,n,world", [(4, 6, 2), (4, 7, 3), (2, 8, 4), (3, 6, 2)])
+@pytest.mark.parametrize("p,n,world,first", [(4, 6, 2, None), (4, 7, 3, None), (2, 8, 4, None), (3, 6, 2, None),
+                                             (4, 12, 2, [True, True]), (4, 18, 3, [True, False, True]), (4, 24, 3, [True, True, True]),
+                                             (2, 18, 3, [True, True, True])])
 @pytest.mark.parametrize("nt", [mf.F64, mf.F32])
-def test_cxx_slab_exchange_in_process(p, n, world, nt):
+def test_cxx_slab_exchange_in_process(p, n, world, first, nt):
     """the C++ multi-GPU path behind the C-ABI (mfgpu_dist: priority pass 2 of the interface planes, pack, transfer,
     masked add, overlap with the rest of pass 2) on ONE GPU: every slab is an operator + mfgpu_dist of this process,
     connected by the in-process transport -- everything but the two RCCL calls of the real transport.  Three chained
@@ -469,6 +494,17 @@ def test_cxx_slab_exchange_in_process(p, n, world, nt):
         slabs.append(dict(mesh=mesh, op=op, dist=dist, gi=gi, a=a, b=b))
     for lo, up in zip(slabs, slabs[1:]):
         lo["dist"].connect_local(up["dist"])
+    # on slabs thick enough the batches touching an interface plane run first and the exchange
+    # runs beside the interior batches; the interface batches sit at the ends of the plan's batch order
+    for r, s in enumerate(slabs):
+        ifirst, r1, r2, nb = s["dist"].schedule()
+        if first is not None:
+            assert ifirst == first[r], (r, ifirst, r1, r2, nb)
+        if ifirst:
+            assert 0 <= r1 < r2 <= nb and (r2 - r1) * 10 >= nb * 4
+            assert (r1 == 0) == (r == 0) and (r2 == nb) == (r == world - 1)
+        with pytest.raises(mf.MfgpuError):  # one-call form on the in-process transport: peers have not packed yet
+            s["dist"].vmult(s["op"], s["b"], s["a"])
     fx = full.dof_coords()
     x = (np.sin(3 * fx[:, 0]) + fx[:, 1] ** 2 - np.cos(2 * fx[:, 2]) * fx[:, 0]).astype(mf.np_dtype(nt)).astype(np.float64)
     for s in slabs:
