@@ -473,7 +473,7 @@ template <typename T>
 hipError_t planes_launch(mfgpu_handle *h, const ApplyArgs<T> &a0, bool hn, uint32_t grid, hipStream_t st,
                          bool configure_only, size_t *lds_out, int *occupancy) {
   const ApplyArgs<T> &a = a0;
-  return h->qk ? q_launch<T>(h->plan.n, a, h->S.data(), h->Dt.data(), hn, grid, st, configure_only, lds_out, occupancy)
+  return (h->qk || h->plan.n >= 6) ? q_launch<T>(h->plan.n, a, h->S.data(), h->Dt.data(), hn, grid, st, configure_only, lds_out, occupancy)
                : p_launch<T>(h->plan.n, a, h->S.data(), h->Dt.data(), hn, grid, st, configure_only, lds_out, occupancy);
 }
 
@@ -899,7 +899,7 @@ int mfgpu_plan_stats(const mfgpu_handle *h, uint64_t s[8]) {
 
 const char *mfgpu_kernel_name(const mfgpu_handle *h) {
   if (!h) return "";
-  if (h->pk && h->qk) return h->xk ? "apply_planes4+apply_batches_x" : "apply_planes4";
+  if (h->pk && (h->qk || h->n >= 6)) return h->xk ? "apply_planes4+apply_batches_x" : "apply_planes4";
   return h->pk ? (h->xk ? "apply_planes3+apply_batches_x" : "apply_planes3")
                : h->gk ? (h->dim == 2 ? "apply_batches_g2" : "apply_batches_g") : h->xk ? "apply_batches_x" : "apply_batches";
 }

@@ -25,8 +25,9 @@ inline int ipow(int a, int e) {
 // values apart (stride = n mod 32: the 16-lane store groups and 32-lane load groups of the yz-plane stage hit
 // distinct banks).
 constexpr int p_cells_per_wave(int n) { return 64 / n; }
-constexpr int p_ji(int n) { return n == 3 ? 2 : n == 4 ? 5 : 9; }
-constexpr int p_hs(int n) { return n == 3 ? 3 : n == 4 ? 6 : 9; }
+// (n = 6, 7, apply_planes4 only: 10 / 9 cells per wave; sized for 3x3x1 slabs and 2x2x2 cubes of cells)
+constexpr int p_ji(int n) { return n == 3 ? 2 : n == 4 ? 5 : n == 5 ? 9 : n == 6 ? 14 : 23; }
+constexpr int p_hs(int n) { return n == 3 ? 3 : n == 4 ? 6 : n == 5 ? 9 : n == 6 ? 14 : 18; }
 constexpr int p_kgu(int n) { return p_ji(n) + p_hs(n); }
 constexpr int p_cell_stride(int n) {
   int s = n * n * n;
@@ -39,13 +40,13 @@ constexpr int p_cell_stride(int n) {
 // c * SA + ZS * z + const, one of the yz-layout (lane = n c + x) c * SA + x + const: with SA = n and ZS = 1 (mod 32) both
 // are lane + const, i.e. distinct banks in every 32-lane group of a ds_read_b64 and every 16-lane group of a
 // ds_write_b64 (MI355X_MICROARCH.md, LDS table).  (p = 2: the smallest such strides are 99 / 33.)
-constexpr int q_plane_stride(int n) { return n == 5 ? 33 : n == 4 ? 17 : 33; }
+constexpr int q_plane_stride(int n) { return n >= 6 ? 65 : n == 5 ? 33 : n == 4 ? 17 : 33; }
 constexpr int q_cell_stride(int n) { return n * q_plane_stride(n); }
 // apply_planes3 on cells WITH a hanging-node mask: the constrained nodes of a cell get PRIVATE entries behind the
 // batch's dof list (p_priv_max(n) of them per batch), a copy of the gathered values, on which the 1D interpolation
 // passes of resolve_hanging_nodes (hanging_nodes.cuh:617-696) run line by line before the cell stages, and their
 // transposes after them (mfgpu_plan.cpp hn_cell_lines, mfgpu_kernels_p.hip)
-constexpr int p_priv_max(int n) { return n == 5 ? 384 : n == 4 ? 256 : 192; }
+constexpr int p_priv_max(int n) { return n >= 5 ? 384 : n == 4 ? 256 : 192; }
 // ... and its fixed-size per-batch record of 32-bit words, stored [row][lane] (a wave reads a row with one coalesced
 // load, one batch ahead): p_priv_max / 64 rows of copies (private position << 16 | dof-list position), then per
 // direction (x, y, z) kHnOpRounds rounds of line operations, 3 rows each (the n <= 5 private positions of lane's line,

@@ -40,8 +40,7 @@ namespace mfgpu {
 #define MFGPU_PIN_VMEM() __builtin_amdgcn_sched_barrier(0x380)
 
 template <int n, typename T, bool ADD, bool HN>
-__global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2)))
-apply_planes4(const ApplyArgs<T> A, const TablesEO<T, n> tab) {
+__device__ __forceinline__ void planes4_body(const ApplyArgs<T> &A, const TablesEO<T, n> &tab) {
   constexpr int n2 = n * n;
   constexpr int CW = p_cells_per_wave(n);  // cells per wave
   constexpr int NT = CW * n;               // tasks (active lanes) of a full batch
@@ -414,6 +413,41 @@ apply_planes4(const ApplyArgs<T> A, const TablesEO<T, n> tab) {
   }
 }
 
+// p <= 4: two waves per SIMD (<= 256 registers).  p = 5, 6 (n = 6, 7): a plane is 72 / 98 registers and four of them
+// are live in S4 -- one wave per SIMD with the whole register file; the single aliased transpose array is what lets
+// four such workgroups share a CU's LDS at all (34 / 36 KB each).
+template <int n, typename T, bool ADD, bool HN>
+__global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2)))
+apply_planes4(const ApplyArgs<T> A, const TablesEO<T, n> tab) {
+  planes4_body<n, T, ADD, HN>(A, tab);
+}
+template <int n, typename T, bool ADD>
+__global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(1, 1)))
+apply_planes4w(const ApplyArgs<T> A, const TablesEO<T, n> tab) {
+  planes4_body<n, T, ADD, false>(A, tab);
+}
+
+template <int n, typename T>
+static hipError_t q_run_w(const ApplyArgs<T> &a, const double *S, const double *Dt, uint32_t grid, hipStream_t st,
+                          bool configure_only, size_t *lds_out, int *occupancy) {
+  const size_t lds = q_lds_bytes<T>(n, false);
+  if (lds_out) *lds_out = lds;
+  if (configure_only) {
+    hipError_t e = hipFuncSetAttribute((const void *)apply_planes4w<n, T, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    if (e == hipSuccess)
+      e = hipFuncSetAttribute((const void *)apply_planes4w<n, T, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    if (e == hipSuccess && occupancy)
+      e = hipOccupancyMaxActiveBlocksPerMultiprocessor(occupancy, apply_planes4w<n, T, false>, 64, lds);
+    return e;
+  }
+  const TablesEO<T, n> tab = make_tables_eo<T, n>(S, Dt);
+  if (a.add)
+    hipLaunchKernelGGL((apply_planes4w<n, T, true>), dim3(grid), dim3(64), lds, st, a, tab);
+  else
+    hipLaunchKernelGGL((apply_planes4w<n, T, false>), dim3(grid), dim3(64), lds, st, a, tab);
+  return hipGetLastError();
+}
+
 template <int n, typename T>
 static hipError_t q_run(const ApplyArgs<T> &a, const double *S, const double *Dt, bool hn, uint32_t grid, hipStream_t st,
                         bool configure_only, size_t *lds_out, int *occupancy) {
@@ -451,6 +485,8 @@ hipError_t q_launch(int n, const ApplyArgs<T> &a, const double *S, const double 
     case 3: return q_run<3, T>(a, S, Dt, hn, grid, st, configure_only, lds_out, occupancy);
     case 4: return q_run<4, T>(a, S, Dt, hn, grid, st, configure_only, lds_out, occupancy);
     case 5: return q_run<5, T>(a, S, Dt, hn, grid, st, configure_only, lds_out, occupancy);
+    case 6: return hn ? hipErrorInvalidValue : q_run_w<6, T>(a, S, Dt, grid, st, configure_only, lds_out, occupancy);
+    case 7: return hn ? hipErrorInvalidValue : q_run_w<7, T>(a, S, Dt, grid, st, configure_only, lds_out, occupancy);
     default: return hipErrorInvalidValue;
   }
 }

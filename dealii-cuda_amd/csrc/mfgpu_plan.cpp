@@ -693,7 +693,7 @@ int choose_kernel_and_plan(const mfgpu_desc &d, KernelChoice &kc, Plan &plan) {
     return MFGPU_EINVAL;
   }
   // (with hanging nodes: the cells without a mask run in the plane kernel, the masked ones in apply_batches_x)
-  const bool pk_ok = d.dim == 3 && !general && !colored && d.degree >= 2 && d.degree <= 4 &&
+  const bool pk_ok = d.dim == 3 && !general && !colored && d.degree >= 2 && d.degree <= 6 &&
                      d.n_dofs < (1u << 29);  // (vectors are addressed base + 32-bit byte offset)
   const bool xk_ok = d.dim == 3 && !general && !colored;
   const bool want_planes = d.kernel == MFGPU_KERNEL_PLANES || d.kernel == MFGPU_KERNEL_PLANES_2W;
@@ -705,8 +705,9 @@ int choose_kernel_and_plan(const mfgpu_desc &d, KernelChoice &kc, Plan &plan) {
   kc.general = general;
   // by default the plane kernel serves p = 4 only: at p = 2, 3 the pencil kernel measures faster
   // (on meshes with hanging nodes also p = 3: 0.174 instead of 0.256 ms on the bmop ADAPTIVE_GRID mesh, n_ref = 6)
+  // p = 5, 6: apply_planes4 with one wave per SIMD (apply_planes3's two transpose arrays do not fit the LDS there)
   kc.planes = pk_ok && (want_planes ||
-                        (d.kernel == MFGPU_KERNEL_AUTO && (d.degree == 4 || (hn && d.degree == 3))));
+                        (d.kernel == MFGPU_KERNEL_AUTO && (d.degree >= 4 || (hn && d.degree == 3))));
   kc.pencils_x = xk_ok && !kc.planes && d.kernel != MFGPU_KERNEL_PENCILS;
   PlanLimits lim;
   if (kc.planes) {
@@ -717,7 +718,7 @@ int choose_kernel_and_plan(const mfgpu_desc &d, KernelChoice &kc, Plan &plan) {
     lim.shared_max = lim.halo_stride - 1u;  // the list's last slot stays padding (idle tasks)
     lim.segregate_masked = hn;
     // cells with a hanging-node mask run in the plane kernel too (apply_planes3<HN>), in batches of their own
-    lim.masked_planes = hn;
+    lim.masked_planes = hn && d.degree <= 4;  // (p = 5, 6: masked cells stay in the pencil kernel)
     lim.private_max = (uint32_t)p_priv_max(d.degree + 1);
   }
   // apply_batches_x unrolls 4 chunks at p=3 (64-cell batches = 13^3 dofs like p=4); everything else 3
