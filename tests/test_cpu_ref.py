@@ -32,3 +32,18 @@ def test_cpu_ref_protocol_golden():
         y = ref.bmop(k)
         # chained applies of the un-normalised operator amplify rounding differences by ||A|| ~ 100 per apply
         assert np.linalg.norm(y - g[f"prot{k}"]) <= 1e-12 * 100 ** (k - 1) * np.linalg.norm(g[f"prot{k}"])
+
+
+def test_bmop_cpu_driver_runs_baseline_config_1():
+    """BASELINE.json configs[0] as written: `bmop-cpu` built with DEGREE_FE=2, DIMENSION=2, 5 global refinements --
+    bmop-cpu.cc's command line (max_refinement [min_refinement]) and its TSV line dim, degree, n_dofs, s per vmult."""
+    import subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    exe = os.path.join(root, "oracle", "bin", "bmop-cpu-2d-p2")
+    if not os.path.exists(exe):
+        subprocess.check_call(["make", "-C", os.path.join(root, "oracle")])
+    out = subprocess.run([exe, "5", "4"], stdout=subprocess.PIPE, text=True, timeout=300, check=True).stdout.strip().split("\n")
+    assert len(out) == 2
+    for line, ndofs in zip(out, (33 * 33, 65 * 65)):
+        f = line.split("\t")
+        assert f[:3] == ["2", "2", str(ndofs)] and float(f[3]) > 0.0
