@@ -144,9 +144,15 @@ __device__ __forceinline__ void lds_add(T *p, T v) {
       A.stamps[(size_t)b * 16 + (k)] = t_;                                                \
     }                                                                                     \
   } while (0)
+// which workgroup ran the batch
+#define WGSTAMP(k)                                                                        \
+  do {                                                                                    \
+    if (A.stamps && threadIdx.x == 0) A.stamps[(size_t)b * 16 + (k)] = blockIdx.x + 1;    \
+  } while (0)
 #else
 #define RSTAMP(k)
 #define STAMP(k)
+#define WGSTAMP(k)
 #define DBG(bit) 0
 #endif
 

@@ -244,9 +244,7 @@ apply_planes3(const ApplyArgs<T> A, const TablesEO<T, n> tab) {
     }
     STAMP(0);
     RSTAMP(8);
-#ifdef MFGPU_STAMPS
-    if (A.stamps && threadIdx.x == 0) A.stamps[(size_t)b * 16 + 10] = blockIdx.x + 1;
-#endif
+    WGSTAMP(10);
     // ---- coalesced loads of the coming batches: dof list two ahead, index runs one ahead
     load_dofs(b2, Gnn);
     load_ix(b1, IXn);
@@ -263,22 +261,14 @@ apply_planes3(const ApplyArgs<T> A, const TablesEO<T, n> tab) {
       MFGPU_PIN_VMEM();
 #pragma unroll
       for (int j = (KGU * s) / (2 * n); j < (KGU * (s + 1)) / (2 * n); ++j)
-#if defined(MFGPU_ABL) && (MFGPU_ABL & 1)  // ablation builds (tools/ablate_p.sh), never the product
-        SVn[j] = (T)Gn[j];
-#else
         SVn[j] = src_at(Gn[j]);
-#endif
       MFGPU_PIN_VMEM();
     };
     auto hookB = [&](int s) {  // 5 n steps: the previous batch's scatter
       MFGPU_PIN_VMEM();
 #pragma unroll
       for (int j = (KGU * s) / (5 * n); j < (KGU * (s + 1)) / (5 * n); ++j)
-#if defined(MFGPU_ABL) && (MFGPU_ABL & 2)
-        asm volatile("" ::"v"(R[j]), "v"(Gp[j]));
-#else
         scatter_slot(j, bp, Gp[j], R[j], old[j]);
-#endif
       MFGPU_PIN_VMEM();
     };
     const T *const cnext = A.coefp + (size_t)b1 * (n2 * NT) + tk;
@@ -286,11 +276,7 @@ apply_planes3(const ApplyArgs<T> A, const TablesEO<T, n> tab) {
       MFGPU_PIN_VMEM();
 #pragma unroll
       for (int r = (n2 * s) / (2 * n); r < (n2 * (s + 1)) / (2 * n); ++r)
-#if defined(MFGPU_ABL) && (MFGPU_ABL & 4)
-        asm volatile("" : "+v"(Cc[r]) : "v"(cnext));
-#else
         Cc[r] = nt_load(cnext + r * NT);
-#endif
       MFGPU_PIN_VMEM();
     };
 
