@@ -44,6 +44,7 @@ def run():
     n = int(sys.argv[2]) if len(sys.argv) > 2 else 54
     p = int(sys.argv[3]) if len(sys.argv) > 3 else 4
     mesh = mf.Mesh.uniform(3, p, n)
+    mesh.desc.kernel = mf.KERNEL_PLANES_2W
     op = mf.Operator(mesh.desc, mesh)
     assert op.kernel_name() == "apply_planes4"
     L = mf.lib()
@@ -76,6 +77,11 @@ def run():
         last[w] = max(last.get(w, 0), e)
     f = np.array([first[w] for w in sorted(first)]) / 100.0
     l = np.array([last[w] for w in sorted(first)]) / 100.0
+    ws = np.array(sorted(first))
+    for x in range(8):
+        m = (ws % 8) == x
+        print(f"  workgroups = {x} (mod 8): last batch ends (us) p10 {np.percentile(l[m], 10):.1f} p50 {np.percentile(l[m], 50):.1f} "
+              f"p90 {np.percentile(l[m], 90):.1f} max {l[m].max():.1f}")
     print(f"{len(f)} workgroups; first batch starts (us): p50 {np.percentile(f, 50):.1f} max {f.max():.1f}; "
           f"last batch ends (us): min {l.min():.1f} p10 {np.percentile(l, 10):.1f} p50 {np.percentile(l, 50):.1f} p90 {np.percentile(l, 90):.1f} max {l.max():.1f}")
 
