@@ -12,7 +12,7 @@ timeout -k 5 200 rocprofv3 --pmc SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_ACTIV
 timeout -k 5 200 rocprofv3 --pmc SQ_INSTS_VALU SQ_INSTS_LDS SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_INSTS_SALU SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_WAIT_INST_LDS --output-format csv -d $O/sq2 -- $P > $O/sq2.log 2>&1; echo "sq2 rc=$?"
 timeout -k 5 200 rocprofv3 --pmc SQ_ACTIVE_INST_VMEM SQ_ACTIVE_INST_SCA SQ_ACTIVE_INST_MISC SQ_INST_CYCLES_VMEM SQ_LDS_ADDR_CONFLICT SQ_LDS_DATA_FIFO_FULL SQ_LDS_CMD_FIFO_FULL SQ_LDS_UNALIGNED_STALL --output-format csv -d $O/sq3 -- $P > $O/sq3.log 2>&1; echo "sq3 rc=$?"
 timeout -k 5 200 rocprofv3 --pmc TA_TA_BUSY_sum TA_BUSY_avr TCP_PENDING_STALL_CYCLES_sum TCC_HIT_sum TCC_MISS_sum --output-format csv -d $O/ta -- $P > $O/ta.log 2>&1; echo "ta rc=$?"
-python3 $R/tools/pmc_summary.py $O apply_planes > $O/summary.txt 2>&1
+python3 $R/tools/pmc_summary.py $O ${PMC_KERNEL:-apply_planes} > $O/summary.txt 2>&1
 python3 - <<PY >> $O/summary.txt
 import csv,glob
 for f in glob.glob("$O/kt/*/*kernel_trace.csv"):
