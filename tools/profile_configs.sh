@@ -12,3 +12,4 @@ run() {  # name, bench args...
   echo "$name done: $(cut -c1-200 $R/gpurun_out/${TAG}_${name}_line.json | grep -o '"ms_per_step": [0-9.]*')"
 }
 run c3 --adaptive 6 && run c5 --degree 6 --cells 36 && run float --float && run ball --ball 5 && run general --general-jacobian 0.1
+run n64 --cells 64 && run n108 --cells 108 && run p5 --degree 5 --cells 43 && run planes2w --kernel planes_2w
