@@ -473,7 +473,7 @@ template <typename T>
 hipError_t planes_launch(mfgpu_handle *h, const ApplyArgs<T> &a0, bool hn, uint32_t grid, hipStream_t st,
                          bool configure_only, size_t *lds_out, int *occupancy) {
   const ApplyArgs<T> &a = a0;
-  return (h->qk || h->plan.n >= 6) ? q_launch<T>(h->plan.n, a, h->S.data(), h->Dt.data(), hn, grid, st, configure_only, lds_out, occupancy)
+  return h->qk ? q_launch<T>(h->plan.n, a, h->S.data(), h->Dt.data(), hn, grid, st, configure_only, lds_out, occupancy)
                : p_launch<T>(h->plan.n, a, h->S.data(), h->Dt.data(), hn, grid, st, configure_only, lds_out, occupancy);
 }
 
@@ -773,7 +773,10 @@ int mfgpu_create(const mfgpu_desc *desc, mfgpu_handle **out) {
   int rc = choose_kernel_and_plan(d, kc, h->plan);
   h->gk = kc.general;
   h->pk = kc.planes;
-  h->qk = d.kernel == MFGPU_KERNEL_PLANES_2W;
+  // which plane kernel: apply_planes4 on request, at p = 5, 6 (the only one that fits), and by default at p = 3 in
+  // double; apply_planes3 otherwise (p = 4: equal in double, faster in float)
+  h->qk = d.kernel == MFGPU_KERNEL_PLANES_2W || d.degree >= 5 ||
+          (d.kernel == MFGPU_KERNEL_AUTO && d.degree == 3 && d.number_type == MFGPU_F64);
   h->xk = kc.pencils_x;
   if (rc) {
     delete h;
@@ -899,7 +902,7 @@ int mfgpu_plan_stats(const mfgpu_handle *h, uint64_t s[8]) {
 
 const char *mfgpu_kernel_name(const mfgpu_handle *h) {
   if (!h) return "";
-  if (h->pk && (h->qk || h->n >= 6)) return h->xk ? "apply_planes4+apply_batches_x" : "apply_planes4";
+  if (h->pk && h->qk) return h->xk ? "apply_planes4+apply_batches_x" : "apply_planes4";
   return h->pk ? (h->xk ? "apply_planes3+apply_batches_x" : "apply_planes3")
                : h->gk ? (h->dim == 2 ? "apply_batches_g2" : "apply_batches_g") : h->xk ? "apply_batches_x" : "apply_batches";
 }

@@ -706,8 +706,9 @@ int choose_kernel_and_plan(const mfgpu_desc &d, KernelChoice &kc, Plan &plan) {
   // by default the plane kernel serves p = 4 only: at p = 2, 3 the pencil kernel measures faster
   // (on meshes with hanging nodes also p = 3: 0.174 instead of 0.256 ms on the bmop ADAPTIVE_GRID mesh, n_ref = 6)
   // p = 5, 6: apply_planes4 with one wave per SIMD (apply_planes3's two transpose arrays do not fit the LDS there)
-  kc.planes = pk_ok && (want_planes ||
-                        (d.kernel == MFGPU_KERNEL_AUTO && (d.degree >= 4 || (hn && d.degree == 3))));
+  // p = 3: apply_planes4 with two waves per SIMD (16 cells per wave) measures 9 % faster than the pencil kernel per
+  // vmult (0.222 vs 0.243 ms at 10^7 dofs; profiles/r03_notes.md); p = 2: the pencil kernel stays ahead
+  kc.planes = pk_ok && (want_planes || (d.kernel == MFGPU_KERNEL_AUTO && d.degree >= 3));
   kc.pencils_x = xk_ok && !kc.planes && d.kernel != MFGPU_KERNEL_PENCILS;
   PlanLimits lim;
   if (kc.planes) {

@@ -327,14 +327,15 @@ def test_adaptive_mesh_with_hanging_nodes(dim, p, nref, colored):
 @pytest.mark.parametrize("p,nref", [(4, 4), (2, 4), (3, 5)])
 @pytest.mark.parametrize("xk", [True, False])
 def test_adaptive_mesh_both_cell_loop_kernels(p, nref, xk):
-    """3D two-pass default on meshes with hanging nodes: apply_planes3 at p = 4 (cells with a mask in batches of their
-    own, apply_planes3<HN>), apply_batches_x otherwise; mfgpu_desc.kernel = PENCILS selects apply_batches (which also
+    """3D two-pass default on meshes with hanging nodes: apply_planes3 at p = 4, apply_planes4 at p = 3 (cells with a mask
+    in batches of their own, <HN>), apply_batches_x otherwise; mfgpu_desc.kernel = PENCILS selects apply_batches (which also
     serves 2D and the coloured mode), PENCILS_X the pencil kernel at p = 4 too: same operator on an adaptive mesh."""
     mesh = mf.Mesh.adaptive(3, p, nref)
     od = oracle_desc_from_mesh(mesh, dtype=np.float64)
     mesh.desc.kernel = mf.KERNEL_AUTO if xk else mf.KERNEL_PENCILS
     op = mf.Operator(mesh.desc, mesh)
-    assert op.kernel_name() == (("apply_planes3" if p >= 3 else "apply_batches_x") if xk else "apply_batches")
+    auto = {4: "apply_planes3", 3: "apply_planes4", 2: "apply_batches_x"}[p]  # (p = 3 in double: apply_planes4)
+    assert op.kernel_name() == (auto if xk else "apply_batches")
     rng = np.random.default_rng(5)
     x, y0 = rng.standard_normal(mesh.n_dofs), rng.standard_normal(mesh.n_dofs)
     assert rel(gpu_vmult(op, x), o.vmult(od, x)) <= 1e-12
