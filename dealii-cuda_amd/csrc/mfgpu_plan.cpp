@@ -708,7 +708,9 @@ int choose_kernel_and_plan(const mfgpu_desc &d, KernelChoice &kc, Plan &plan) {
   // p = 5, 6: apply_planes4 with one wave per SIMD (apply_planes3's two transpose arrays do not fit the LDS there)
   // p = 3: apply_planes4 with two waves per SIMD (16 cells per wave) measures 9 % faster than the pencil kernel per
   // vmult (0.222 vs 0.243 ms at 10^7 dofs; profiles/r03_notes.md); p = 2: the pencil kernel stays ahead
-  kc.planes = pk_ok && (want_planes || (d.kernel == MFGPU_KERNEL_AUTO && d.degree >= 3));
+  // (in float the pencil kernel is ahead at p = 3 on conforming meshes: 0.152 vs 0.179 ms)
+  kc.planes = pk_ok && (want_planes || (d.kernel == MFGPU_KERNEL_AUTO &&
+                                        (d.degree >= 4 || (d.degree == 3 && (hn || d.number_type == MFGPU_F64)))));
   kc.pencils_x = xk_ok && !kc.planes && d.kernel != MFGPU_KERNEL_PENCILS;
   PlanLimits lim;
   if (kc.planes) {
