@@ -148,7 +148,13 @@ __device__ __forceinline__ void planes4_body(const ApplyArgs<T> &A, const Tables
   if (HN) load_hn(b, Hc);
 #pragma unroll
   for (int j = 0; j < KGU; ++j) SV[j] = src_at(Gc[j]);
-  load_coef(b, Cc);
+  // Coefficient rows: requested a batch ahead, inside S5 (two waves per SIMD: the registers are free from S5 on and the
+  // sibling wave covers the burst) -- or, with one wave per SIMD (n >= 6), THIS batch's rows during S1, one or two
+  // between the contractions: the lone wave is blocked ~150 cycles by every vector-memory instruction it issues right
+  // behind another one, and S5 already carries the next batch's gathers and index runs (stamp build: S5 took 25 k of
+  // 53 k cycles per batch with all 115 loads in it).  S1 is 5 k cycles long: the rows are there when S2 needs them.
+  constexpr bool kCoefInS1 = n >= 6;
+  if (!kCoefInS1) load_coef(b, Cc);
 #pragma unroll
   for (int w = 0; w < NIW; ++w) IXc[w] = lane_on ? IXc[w] : kDummyIx;
 
@@ -210,6 +216,13 @@ __device__ __forceinline__ void planes4_body(const ApplyArgs<T> &A, const Tables
       WaveSync::sync();
     }
 
+    const T *const cthis = A.coefp + (size_t)b * (n2 * NT) + tk;
+    auto hook_coef = [&](int s) {  // step s of the 2 n steps of S1 (kCoefInS1)
+      MFGPU_PIN_VMEM();
+#pragma unroll
+      for (int r = (n2 * s) / (2 * n); r < (n2 * (s + 1)) / (2 * n); ++r) Cc[r] = nt_load(cthis + r * NT);
+      MFGPU_PIN_VMEM();
+    };
     // ---- S1 (xy): gather the plane, S_y, then per line S_x (kept) and D_x (-> T)
     T u[n2];
 #pragma unroll
@@ -222,6 +235,7 @@ __device__ __forceinline__ void planes4_body(const ApplyArgs<T> &A, const Tables
       get_line<n, 1>(u, x, in);
       eo_apply<n, 0>(tab, in, out);
       set_line<n, 1>(u, x, out);
+      if (kCoefInS1) hook_coef(x);
     }
 #pragma unroll
     for (int y = 0; y < n; ++y) {
@@ -232,6 +246,7 @@ __device__ __forceinline__ void planes4_body(const ApplyArgs<T> &A, const Tables
       set_line<n, 0>(u, y, a);
 #pragma unroll
       for (int x = 0; x < n; ++x) Tw[pxy + x + n * y] = bb[x];
+      if (kCoefInS1) hook_coef(n + y);
     }
     WaveSync::sync();
 
@@ -324,13 +339,13 @@ __device__ __forceinline__ void planes4_body(const ApplyArgs<T> &A, const Tables
     const T *const cnext = A.coefp + (size_t)b1 * (n2 * NT) + tk;
     const uint32_t *const ixnext = A.idxp + (size_t)b1 * (NIW * NT) + tk;
     auto hook = [&](int s) {  // step s of 2 n: gathers first (consumed first), then index runs, then coefficient rows
-      constexpr int NL = KGU + NIW + n2;
+      constexpr int NL = KGU + NIW + (kCoefInS1 ? 0 : n2);
       MFGPU_PIN_VMEM();
 #pragma unroll
       for (int i = (NL * s) / (2 * n); i < (NL * (s + 1)) / (2 * n); ++i) {
         if (i < KGU) SV[i] = src_at(Gn[i]);
         else if (i < KGU + NIW) IXn[i - KGU] = nt_load(ixnext + (i - KGU) * NT);
-        else Cc[i - KGU - NIW] = nt_load(cnext + (i - KGU - NIW) * NT);
+        else if (!kCoefInS1) Cc[i - KGU - NIW] = nt_load(cnext + (i - KGU - NIW) * NT);
       }
       MFGPU_PIN_VMEM();
     };
