@@ -342,6 +342,22 @@ def test_adaptive_mesh_both_cell_loop_kernels(p, nref, xk):
     assert rel(gpu_vmult(op, x, y0=y0), o.vmult_add(od, y0, x)) <= 1e-12
 
 
+@pytest.mark.parametrize("p,nref,nt", [(5, 4, mf.F64), (6, 4, mf.F64), (5, 4, mf.F32)])
+def test_adaptive_mesh_high_degree_two_families(p, nref, nt):
+    """p = 5, 6 on a mesh with hanging nodes: the cells without a constraint mask run in the plane kernel
+    (apply_planes4w, one wave per SIMD), the masked ones in the pencil kernel's hanging-node variant; vmult and
+    vmult_add against the oracle"""
+    mesh = mf.Mesh.adaptive(3, p, nref, number_type=nt)
+    od = oracle_desc_from_mesh(mesh, dtype=np.float64)
+    op = mf.Operator(mesh.desc, mesh)
+    assert op.kernel_name() == "apply_planes4+apply_batches_x"
+    rng = np.random.default_rng(p)
+    x, y0 = rng.standard_normal(mesh.n_dofs), rng.standard_normal(mesh.n_dofs)
+    xt, y0t = (v.astype(mf.np_dtype(nt)).astype(np.float64) for v in (x, y0))
+    assert rel(gpu_vmult(op, x, nt), o.vmult(od, xt)) <= TOL[nt]
+    assert rel(gpu_vmult(op, x, nt, y0=y0), o.vmult_add(od, y0t, xt)) <= TOL[nt]
+
+
 @pytest.mark.parametrize("p,nref", [(4, 4), (4, 5), (2, 5), (3, 5)])
 @pytest.mark.parametrize("kern", [mf.KERNEL_AUTO, mf.KERNEL_PENCILS_X, mf.KERNEL_PENCILS],
                          ids=["auto", "apply_batches_x", "apply_batches"])
