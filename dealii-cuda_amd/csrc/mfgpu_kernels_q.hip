@@ -1,5 +1,6 @@
-// 3D cell-loop kernel, two-pass scatter mode, uniform-Jacobian path: a thread owns a 2D PLANE of a cell, TWO waves per
-// SIMD (apply_planes4; round 3).
+// 3D cell-loop kernel, two-pass scatter mode, uniform-Jacobian path: a thread owns a 2D PLANE of a cell; ONE LDS
+// transpose array (apply_planes4, round 3).  Default at p = 3 in double (two waves per SIMD) and at p = 5, 6 (one wave
+// per SIMD, apply_planes4w); on request at p = 2, 4 (MFGPU_KERNEL_PLANES_2W).
 //
 // apply_planes3 (mfgpu_kernels_p.hip, round 2) runs ONE wave per SIMD: two LDS transpose arrays of 12 cells plus the
 // batch array are 36.9 KB per wave and its prefetch state ~330 registers.  Its ablation (profiles/r02_notes.md section 2)
@@ -21,9 +22,14 @@
 //   S5 (xy):               out = S_y^T S_x^T (w + T);  ua <- 0;  ua += out
 //
 //     14 contractions per cell as before (reference: 18, tensor_ops.cuh:179-261); 5 LDS stores + 1 LDS add per value.
-//   * prefetch state cut to what the sibling wave cannot hide: dof list, source values, index runs and coefficient
-//     rows of the NEXT batch only, requested before S5, when the coefficient registers of this batch are dead; the
-//     results are stored at the end of their own iteration.  <= 256 registers.
+//   * prefetch state cut to the NEXT batch only: its dof list (requested before S3), source values and index runs
+//     (requested inside S5, between the contractions) and coefficient rows (inside S5 as well, when this batch's are
+//     dead -- or, with one wave per SIMD, the batch's own rows during its S1); the results are stored at the end of
+//     their own iteration.  <= 256 registers at p <= 4.
+//
+// What it bought (profiles/r03_notes.md): at p = 4 in double NOTHING (equal to apply_planes3: the floor there is FP64
+// issue, and two in-order waves running the same phases overlap little); p = 3: 9-12 % per vmult over the pencil kernel
+// and apply_planes3; p = 5, 6: a plane kernel at all (apply_planes3's two arrays would be 73 KB per wave): C5 -18 %.
 //
 // Algebra per cell: fee_gpu.cuh:219-284 (uniform-Jacobian branch), tensor_ops.cuh:179-261;
 // gather / scatter: fee_gpu.cuh:323-363; constrained rows: constraint_handler_gpu.cu:247-289;
