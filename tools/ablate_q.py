@@ -14,36 +14,33 @@ import sys
 
 R = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 SRC = os.path.join(R, "dealii-cuda_amd", "csrc", "mfgpu_kernels_q.hip")
-VARIANTS = {"x4c": ["x4c"], "x4ci": ["x4c", "x4i"], "nocoef": ["coef"], "nomem": ["gather", "store", "coef", "rec"],
-            "nolds": ["gather", "store", "coef", "rec", "lds"]}
+VARIANTS = {"nomem": ["gather", "store", "coef", "rec"], "nolds": ["gather", "store", "coef", "rec", "lds"],
+            "valu": ["gather", "store", "coef", "rec", "lds", "ua"]}
 
 PATCH = {
-    "gather": [("    for (int j = 0; j < KGU; ++j) SV[j] = src_at(Gn[j]);\n",
-                "    for (int j = 0; j < KGU; ++j) SV[j] = (T)(Gn[j] & 1023u);\n")],
+    "gather": [("        if (i < KGU) SV[i] = src_at(Gn[i]);\n", "        if (i < KGU) SV[i] = (T)(Gn[i] & 1023u);\n")],
     "store": [("          *p = ADD ? *p + r : r;\n", "          asm volatile(\"\" ::\"v\"(r), \"v\"(p));\n"),
               ("          hp[(j - JI) * 64] = r;\n", "          asm volatile(\"\" ::\"v\"(r), \"v\"(hp));\n")],
-    "coef": [("    load_coef(b1, Cc);\n",
-              "    for (int r = 0; r < n2; ++r) asm volatile(\"\" : \"+v\"(Cc[r]));\n")],
-    "rec": [("    load_dofs(b1, Gn);\n    load_ix(b1, IXn);\n",
-             "    for (int j = 0; j < KGU; ++j) { Gn[j] = Gc[j]; asm volatile(\"\" : \"+v\"(Gn[j])); }\n"
-             "    for (int w3 = 0; w3 < NIW; ++w3) { IXn[w3] = IXc[w3]; asm volatile(\"\" : \"+v\"(IXn[w3])); }\n")],
-    # what 16-byte loads of the coalesced streams would buy: the SAME bytes (permuted within the batch's records: wrong
-    # results, valid addresses) with 13 + 5 + 4 instead of 25 + 18 + 13 load instructions
-    "x4c": [("    for (int r = 0; r < n2; ++r) c[r] = nt_load(p + r * NT);\n",
-            "    for (int r = 0; r < (n2 + 1) / 2; ++r) {\n"
-            "      const size_t o = (size_t)(2 * r * 64 + 2 * lane) < (size_t)(n2 * NT - 2) ? (size_t)(2 * r * 64 + 2 * lane) : (size_t)(n2 * NT - 2);\n"
-            "      typedef double d2_t __attribute__((ext_vector_type(2)));\n      const d2_t v = nt_load(reinterpret_cast<const d2_t *>(A.coefp + (size_t)bb * (n2 * NT) + o));\n"
-            "      c[2 * r] = (T)v.x;\n      if (2 * r + 1 < n2) c[2 * r + 1] = (T)v.y;\n    }\n")],
-    "x4i": [
-           ("    for (int w = 0; w < NIW; ++w) ix[w] = nt_load(p + w * NT);\n",
-            "    for (int w = 0; w < (NIW + 3) / 4; ++w) {\n"
-            "      const uint32_t o = (uint32_t)(w * 256 + 4 * lane) < (uint32_t)(NIW * NT - 4) ? (uint32_t)(w * 256 + 4 * lane) : (uint32_t)(NIW * NT - 4);\n"
-            "      typedef unsigned u4_t __attribute__((ext_vector_type(4)));\n      const u4_t v = nt_load(reinterpret_cast<const u4_t *>(A.idxp + (size_t)bb * (NIW * NT) + o));\n"
-            "      ix[4 * w] = v.x;\n      if (4 * w + 1 < NIW) ix[4 * w + 1] = v.y;\n      if (4 * w + 2 < NIW) ix[4 * w + 2] = v.z;\n      if (4 * w + 3 < NIW) ix[4 * w + 3] = v.w;\n    }\n")],
+    "coef": [("        else if (!kCoefInS1) Cc[i - KGU - NIW] = nt_load(cnext + (i - KGU - NIW) * NT);\n",
+              "        else if (!kCoefInS1) asm volatile(\"\" : \"+v\"(Cc[i - KGU - NIW]));\n"),
+             ("      for (int r = (n2 * s) / (2 * n); r < (n2 * (s + 1)) / (2 * n); ++r) Cc[r] = nt_load(cthis + r * NT);\n",
+              "      for (int r = (n2 * s) / (2 * n); r < (n2 * (s + 1)) / (2 * n); ++r) asm volatile(\"\" : \"+v\"(Cc[r]));\n")],
+    "rec": [("        else if (i < KGU + NIW) IXn[i - KGU] = nt_load(ixnext + (i - KGU) * NT);\n",
+             "        else if (i < KGU + NIW) { IXn[i - KGU] = IXc[i - KGU]; asm volatile(\"\" : \"+v\"(IXn[i - KGU])); }\n"),
+            ("    uint32_t Gn[KGU];\n    load_dofs(b1, Gn);\n",
+             "    uint32_t Gn[KGU];\n    for (int j = 0; j < KGU; ++j) { Gn[j] = Gc[j]; asm volatile(\"\" : \"+v\"(Gn[j])); }\n")],
     # transposes: every Tw access becomes a register move kept alive (wrong results, same arithmetic)
     "lds": [(re.compile(r"(\w+(?:\[\w+\])+) = Tw\[[^;]*\];"), r'{ \1 = (T)lane; asm volatile("" : "+v"(\1)); }'),
             (re.compile(r"Tw\[[^;=]*\] = ([^;]*);"), r'asm volatile("" ::"v"(\1));'),
             (re.compile(r"lds_add\(&Tw\[[^;]*\], ([^;]*)\);"), r'asm volatile("" ::"v"(\1));')],
+    # ... and the batch array (gathered values -> planes, zero, accumulate, results): arithmetic only is left
+    "ua": [("      ua[lane + j * 64] = v;\n", "      asm volatile(\"\" ::\"v\"(v));\n"),
+           ("      u[i] = (T) * reinterpret_cast<const double *>(reinterpret_cast<const char *>(ua) + ixb(IXc, i));\n",
+            "      { u[i] = (T)(lane + i + ixb(IXc, i)); asm volatile(\"\" : \"+v\"(u[i])); }\n"),
+           ("    for (int j = 0; j < (NUA + 63) / 64; ++j) ua[lane + j * 64] = 0.0;\n", "    for (int j = 0; j < 1; ++j) {}\n"),
+           ("      lds_add(reinterpret_cast<double *>(reinterpret_cast<char *>(ua) + ixb(IXc, i)), (double)w[i]);\n",
+            "      asm volatile(\"\" ::\"v\"(w[i]), \"v\"(ixb(IXc, i)));\n"),
+           ("        const T r = (T)ua[lane + j * 64];\n", "        T r = (T)(lane + j); asm volatile(\"\" : \"+v\"(r));\n")],
 }
 
 
@@ -83,7 +80,7 @@ def run():
         lib = os.path.join(R, "dealii-cuda_amd", "lib", "libmfgpu.so" if name == "full" else f"libmfgpu_ablq_{name}.so")
         env = dict(os.environ, MFGPU_LIB=lib)
         out = subprocess.run([sys.executable, os.path.join(R, "bench.py"), "--steps", "30", "--warmup", "3", "--no-cpu",
-                              "--no-second-line"] + sys.argv[2:], env=env, stdout=subprocess.PIPE, stderr=subprocess.DEVNULL, text=True).stdout
+                              "--no-second-line", "--kernel", "planes_2w"] + sys.argv[2:], env=env, stdout=subprocess.PIPE, stderr=subprocess.DEVNULL, text=True).stdout
         m = re.search(r'"avg_launch_us": ([0-9.]+)', out)
         print(f"{name:10s} avg_launch_us {m.group(1) if m else '??'}", flush=True)
 
