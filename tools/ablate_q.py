@@ -14,7 +14,7 @@ import sys
 
 R = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 SRC = os.path.join(R, "dealii-cuda_amd", "csrc", "mfgpu_kernels_q.hip")
-VARIANTS = {"nomem": ["gather", "store", "coef", "rec"], "nolds": ["gather", "store", "coef", "rec", "lds"],
+VARIANTS = {"stagger": ["stagger"], "stagger2": ["stagger2"], "nomem": ["gather", "store", "coef", "rec"], "nolds": ["gather", "store", "coef", "rec", "lds"],
             "valu": ["gather", "store", "coef", "rec", "lds", "ua"]}
 
 PATCH = {
@@ -29,6 +29,9 @@ PATCH = {
              "        else if (i < KGU + NIW) { IXn[i - KGU] = IXc[i - KGU]; asm volatile(\"\" : \"+v\"(IXn[i - KGU])); }\n"),
             ("    uint32_t Gn[KGU];\n    load_dofs(b1, Gn);\n",
              "    uint32_t Gn[KGU];\n    for (int j = 0; j < KGU; ++j) { Gn[j] = Gc[j]; asm volatile(\"\" : \"+v\"(Gn[j])); }\n")],
+    # experiment: the second half of the grid (the second wave of every SIMD) starts half a batch later
+    "stagger": [("  if (b >= bend) return;\n", "  if (b >= bend) return;\n  if (blockIdx.x >= gridDim.x / 2) __builtin_amdgcn_s_sleep(110);\n")],
+    "stagger2": [("  if (b >= bend) return;\n", "  if (b >= bend) return;\n  if (blockIdx.x & 1) { __builtin_amdgcn_s_sleep(110); }\n")],
     # transposes: every Tw access becomes a register move kept alive (wrong results, same arithmetic)
     "lds": [(re.compile(r"(\w+(?:\[\w+\])+) = Tw\[[^;]*\];"), r'{ \1 = (T)lane; asm volatile("" : "+v"(\1)); }'),
             (re.compile(r"Tw\[[^;=]*\] = ([^;]*);"), r'asm volatile("" ::"v"(\1));'),
