@@ -170,11 +170,19 @@ def main():
     _imports()
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU (the HIP path has no CPU fallback)")
+    # tests/test_gpu_dist_rccl_path.py runs the N > 1 path on ONE GPU: every rank on device 0, the torch process group
+    # over gloo, the library's RCCL calls on a preloaded test double (never set outside that test)
+    one_gpu_test = world > 1 and os.environ.get("MFGPU_BENCH_TEST_ONE_GPU") == "1"
+    if one_gpu_test:
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+        if one_gpu_test:
+            dist.init_process_group("gloo", rank=rank, world_size=world)
+        else:
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
 
     nt = mf.F32 if args.float else mf.F64
     tdt = torch.float32 if args.float else torch.float64

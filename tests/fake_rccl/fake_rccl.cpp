@@ -5,8 +5,8 @@
 // a send = stream sync + device-to-host copy into the pair's slot + sequence flag; a recv = wait for the flag +
 // host-to-device copy.  ncclGroupEnd runs the group's sends, then its receives (no deadlock between two ranks that
 // both send first), and synchronises the stream: coarser than RCCL in time, identical in what lands where.
+#include <dlfcn.h>
 #include <fcntl.h>
-#include <hip/hip_runtime.h>
 #include <sys/mman.h>
 #include <unistd.h>
 
@@ -25,6 +25,37 @@ typedef struct { char internal[128]; } ncclUniqueId;
 struct fake_comm;
 typedef struct fake_comm *ncclComm_t;
 }
+
+// The HIP runtime is NOT linked: the three calls are looked up at run time in whatever HIP runtime the process has
+// loaded (PyTorch bundles its own libamdhip64; a second runtime in the process would not know libmfgpu's kernels).
+typedef void *hipStream_t;
+namespace {
+typedef int (*memcpy_fn)(void *, const void *, size_t, int);
+typedef int (*memcpy_async_fn)(void *, const void *, size_t, int, hipStream_t);
+typedef int (*sync_fn)(hipStream_t);
+template <typename F>
+F hip_sym(const char *name) {
+  void *p = dlsym(RTLD_DEFAULT, name);
+  if (!p) {  // loaded RTLD_LOCAL (a dependency of a ctypes-loaded library): ask the already-loaded runtime itself
+    for (const char *lib : {"libamdhip64.so.7", "libamdhip64.so.6", "libamdhip64.so"}) {
+      void *h = dlopen(lib, RTLD_NOLOAD | RTLD_NOW);
+      if (h && (p = dlsym(h, name))) break;
+    }
+  }
+  if (!p) {
+    std::fprintf(stderr, "fake_rccl: %s not found (no HIP runtime loaded yet?)\n", name);
+    std::abort();
+  }
+  return (F)p;
+}
+int hipMemcpy_(void *d, const void *s, size_t n, int kind) { static memcpy_fn f = hip_sym<memcpy_fn>("hipMemcpy"); return f(d, s, n, kind); }
+int hipMemcpyAsync_(void *d, const void *s, size_t n, int kind, hipStream_t st) {
+  static memcpy_async_fn f = hip_sym<memcpy_async_fn>("hipMemcpyAsync");
+  return f(d, s, n, kind, st);
+}
+int hipStreamSynchronize_(hipStream_t st) { static sync_fn f = hip_sym<sync_fn>("hipStreamSynchronize"); return f(st); }
+constexpr int kH2D = 1, kD2H = 2;  // hipMemcpyHostToDevice, hipMemcpyDeviceToHost
+}  // namespace
 
 namespace {
 constexpr size_t kSlotBytes = 8u << 20;  // per ordered pair (src, dst)
@@ -133,8 +164,8 @@ static ncclResult_t run_group(ncclComm_t c) {
       Slot &s = c->slots[(size_t)c->rank * c->world + o.peer];
       const uint64_t n = ++c->sent[o.peer];
       while (s.seq_read.load() < n - 1) usleep(50);  // the previous message of this pair has been taken
-      if (hipStreamSynchronize(o.stream) != hipSuccess) return ncclUnhandledCudaError;  // everything queued before the send
-      if (hipMemcpy(s.data, o.buf, o.bytes, hipMemcpyDeviceToHost) != hipSuccess) return ncclUnhandledCudaError;
+      if (hipStreamSynchronize_(o.stream) != 0) return ncclUnhandledCudaError;  // everything queued before the send
+      if (hipMemcpy_(s.data, o.buf, o.bytes, kD2H) != 0) return ncclUnhandledCudaError;
       s.bytes = o.bytes;
       s.seq_written.store(n);
     }
@@ -144,8 +175,8 @@ static ncclResult_t run_group(ncclComm_t c) {
       const uint64_t n = ++c->received[o.peer];
       while (s.seq_written.load() < n) usleep(50);
       if (s.bytes != o.bytes) return ncclInvalidArgument;  // the two sides disagree on the plane's size
-      if (hipMemcpyAsync(o.buf, s.data, o.bytes, hipMemcpyHostToDevice, o.stream) != hipSuccess) return ncclUnhandledCudaError;
-      if (hipStreamSynchronize(o.stream) != hipSuccess) return ncclUnhandledCudaError;
+      if (hipMemcpyAsync_(o.buf, s.data, o.bytes, kH2D, o.stream) != 0) return ncclUnhandledCudaError;
+      if (hipStreamSynchronize_(o.stream) != 0) return ncclUnhandledCudaError;
       s.seq_read.store(n);
     }
   return ncclSuccess;

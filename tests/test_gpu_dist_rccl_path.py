@@ -24,8 +24,7 @@ HERE = os.path.join(ROOT, "tests", "fake_rccl")
 @pytest.fixture(scope="module")
 def fake_rccl(tmp_path_factory):
     so = str(tmp_path_factory.mktemp("fake_rccl") / "libfake_rccl.so")
-    subprocess.check_call(["hipcc", "-O2", "-fPIC", "-shared", "-o", so, os.path.join(HERE, "fake_rccl.cpp"), "-lrt"],
-                          stderr=subprocess.DEVNULL)
+    subprocess.check_call(["g++", "-O2", "-std=c++17", "-fPIC", "-shared", "-o", so, os.path.join(HERE, "fake_rccl.cpp"), "-lrt", "-ldl"])
     return so
 
 
@@ -56,3 +55,19 @@ def test_rccl_transport_path_between_processes(p, n, world, fake_rccl, tmp_path)
         first.append(bool(d["schedule"][0]))
     if (p, n, world) == (4, 12, 2):
         assert all(first)  # thick slabs: the interface-first schedule ran over this transport
+
+
+def test_bench_multi_rank_path_on_one_gpu(fake_rccl):
+    """bench.py --gpus 2 end to end on the one GPU of the test box: the parent starts the two ranks itself, the ranks
+    build their slabs, rendezvous the communicator id, check one distributed apply against the dense all-reduce of the
+    interface planes, time the steps, and rank 0 prints the JSON line.  (Every rank on device 0, torch process group
+    over gloo, the library's RCCL calls on the test double: MFGPU_BENCH_TEST_ONE_GPU.)"""
+    import json
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    env.update(LD_PRELOAD=fake_rccl, MFGPU_BENCH_TEST_ONE_GPU="1")
+    pr = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "3", "--warmup", "1",
+                         "--cells", "12", "--no-cpu"], env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=600)
+    assert pr.returncode == 0, pr.stderr[-3000:]
+    d = json.loads(pr.stdout.strip().split("\n")[-1])
+    assert d["n_gpus"] == 2 and d["config"]["parallelism"] == "slab2/cxx" and d["config"]["finite"]
+    assert d["config"]["cells_per_dir"] == 15 and d["value"] > 0  # round(12 * 2^(1/3)) cells per direction (weak scaling)
