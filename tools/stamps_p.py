@@ -64,3 +64,12 @@ print(f"first batch starts (us): min {f.min():.1f} p50 {np.percentile(f, 50):.1f
 print(f"last batch ends   (us): min {l.min():.1f} p50 {np.percentile(l, 50):.1f} max {l.max():.1f}")
 print(f"in-batch time per workgroup (us): min {bz.min():.1f} p50 {np.percentile(bz, 50):.1f} max {bz.max():.1f};"
       f" between batches p50 {np.percentile(l - f - bz, 50):.1f}")
+
+# per XCD (workgroups = x mod 8 share one under the dispatcher's round-robin placement) and per CU-sized group
+wsa = np.array(ws)
+for x in range(8):
+    m = (wsa % 8) == x
+    print(f"  workgroups = {x} (mod 8): in-batch time (us) p10 {np.percentile(bz[m], 10):.1f} p50 {np.percentile(bz[m], 50):.1f} "
+          f"p90 {np.percentile(bz[m], 90):.1f}; last batch ends p50 {np.percentile(l[m], 50):.1f} max {l[m].max():.1f}; batches {c[m].sum()}")
+per = bz / c
+print(f"time per batch by workgroup (us): p10 {np.percentile(per, 10):.2f} p50 {np.percentile(per, 50):.2f} p90 {np.percentile(per, 90):.2f} max {per.max():.2f}")
