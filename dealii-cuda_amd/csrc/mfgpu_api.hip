@@ -1,6 +1,8 @@
 // C-ABI entry points (include/mfgpu.h): handle life cycle, vmult / vmult_add, GpuVector pieces.
 #include <hip/hip_runtime.h>
 
+#include <type_traits>
+
 #include <algorithm>
 #include <cmath>
 #include <cstdlib>
@@ -726,6 +728,27 @@ int handle_cells_range(mfgpu_handle *h, uint32_t b0, uint32_t b1, void *dst, con
   hipStream_t st = (hipStream_t)stream;
   if (h->number_type == MFGPU_F64) return launch_cells<double>(h, make_args<double>(h, dst, src, add), b0, b1, st);
   return launch_cells<float>(h, make_args<float>(h, dst, src, add), b0, b1, st);
+}
+// batches [b0, b1) and [c0, c1), b1 <= c0: one launch with a hole when both lie in the plain plane batches
+int handle_cells_two_ranges(mfgpu_handle *h, uint32_t b0, uint32_t b1, uint32_t c0, uint32_t c1, void *dst,
+                            const void *src, void *stream, int add) {
+  const uint32_t nplain = h->pk ? h->plan.n_plain_plane_batches : 0u;
+  if (b0 >= b1 || c0 >= c1 || b1 > c0 || c1 > nplain) {
+    const int rc = handle_cells_range(h, b0, b1, dst, src, stream, add);
+    return rc ? rc : handle_cells_range(h, c0, c1, dst, src, stream, add);
+  }
+  hipStream_t st = (hipStream_t)stream;
+  auto run = [&](auto a) -> int {
+    a.batch0 = b0;
+    a.batch_end = c1;
+    a.hole0 = b1;
+    a.hole_len = c0 - b1;
+    const uint32_t nbat = (b1 - b0) + (c1 - c0);
+    using T = typename std::remove_const<typename std::remove_pointer<decltype(a.src)>::type>::type;
+    HIP_TRY(planes_launch<T>(h, a, false, nbat < h->max_grid_p ? nbat : h->max_grid_p, st, false, nullptr, nullptr));
+    return 0;
+  };
+  return h->number_type == MFGPU_F64 ? run(make_args<double>(h, dst, src, add)) : run(make_args<float>(h, dst, src, add));
 }
 int handle_pass2_group(mfgpu_handle *h, int group, void *dst, const void *src, void *stream, int add) {
   if (!h->twopass) return 0;

@@ -56,9 +56,12 @@ struct mfgpu_dist {
   mfgpu_dist *local_peer[2] = {};       // in-process transport: the lower / upper neighbour's object
   uint32_t n_if[2] = {0, 0};            // interface dofs on the lower / upper plane
   std::vector<uint32_t> ids[2];         // their local dof ids (host copy: priority dofs of the operator)
-  uint32_t *d_ids[2] = {};              // device copy
+  // device copies: ONE allocation each for both planes ([lower | upper]: one pack and one add launch per apply, a tiny
+  // launch costs ~5 us on the stream it sits in); [w] points at plane w's part
+  uint32_t *d_ids[2] = {};
   uint8_t *d_free[2] = {};              // 1: summed with the neighbour, 0: constrained (identity row)
   void *d_send[2] = {}, *d_recv[2] = {};
+  void *d_base[4] = {};                 // the four allocations (ids, free, send, recv)
   hipStream_t side = nullptr;
   hipEvent_t ev_packed = nullptr, ev_done = nullptr, ev_if = nullptr;
   bool in_flight = false;
@@ -83,17 +86,16 @@ __global__ void add_kernel(T *vec, const T *in, const uint32_t *ids, const uint8
 size_t esize(int nt) { return nt == MFGPU_F32 ? 4 : 8; }
 
 int pack_planes(mfgpu_dist *d, const void *vec, hipStream_t st) {
-  for (int w = 0; w < 2; ++w) {
-    if (!d->n_if[w]) continue;
-    const unsigned grid = (d->n_if[w] + 255) / 256;
-    if (d->number_type == MFGPU_F64)
-      hipLaunchKernelGGL(pack_kernel<double>, dim3(grid), dim3(256), 0, st, (double *)d->d_send[w], (const double *)vec,
-                         d->d_ids[w], d->n_if[w]);
-    else
-      hipLaunchKernelGGL(pack_kernel<float>, dim3(grid), dim3(256), 0, st, (float *)d->d_send[w], (const float *)vec,
-                         d->d_ids[w], d->n_if[w]);
-    HIP_TRY(hipGetLastError());
-  }
+  const uint32_t n = d->n_if[0] + d->n_if[1];  // both planes in one launch (contiguous [lower | upper])
+  if (!n) return 0;
+  const unsigned grid = (n + 255) / 256;
+  if (d->number_type == MFGPU_F64)
+    hipLaunchKernelGGL(pack_kernel<double>, dim3(grid), dim3(256), 0, st, (double *)d->d_base[2], (const double *)vec,
+                       (const uint32_t *)d->d_base[0], n);
+  else
+    hipLaunchKernelGGL(pack_kernel<float>, dim3(grid), dim3(256), 0, st, (float *)d->d_base[2], (const float *)vec,
+                       (const uint32_t *)d->d_base[0], n);
+  HIP_TRY(hipGetLastError());
   return 0;
 }
 
@@ -140,15 +142,15 @@ int finish_exchange(mfgpu_dist *d, void *vec, hipStream_t st) {
                              hipMemcpyDeviceToDevice, st));
     }
   }
-  for (int w = 0; w < 2; ++w) {
-    if (!d->n_if[w]) continue;
-    const unsigned grid = (d->n_if[w] + 255) / 256;
+  const uint32_t n = d->n_if[0] + d->n_if[1];  // both planes in one launch (the two planes share no dof)
+  if (n) {
+    const unsigned grid = (n + 255) / 256;
     if (d->number_type == MFGPU_F64)
-      hipLaunchKernelGGL(add_kernel<double>, dim3(grid), dim3(256), 0, st, (double *)vec, (const double *)d->d_recv[w],
-                         d->d_ids[w], d->d_free[w], d->n_if[w]);
+      hipLaunchKernelGGL(add_kernel<double>, dim3(grid), dim3(256), 0, st, (double *)vec, (const double *)d->d_base[3],
+                         (const uint32_t *)d->d_base[0], (const uint8_t *)d->d_base[1], n);
     else
-      hipLaunchKernelGGL(add_kernel<float>, dim3(grid), dim3(256), 0, st, (float *)vec, (const float *)d->d_recv[w],
-                         d->d_ids[w], d->d_free[w], d->n_if[w]);
+      hipLaunchKernelGGL(add_kernel<float>, dim3(grid), dim3(256), 0, st, (float *)vec, (const float *)d->d_base[3],
+                         (const uint32_t *)d->d_base[0], (const uint8_t *)d->d_base[1], n);
     HIP_TRY(hipGetLastError());
   }
   return 0;
@@ -192,25 +194,36 @@ int mfgpu_dist_create(const void *id128, int rank, int world, const uint32_t *lo
     mfgpu_dist_destroy(d);
     return rc;
   };
+  std::vector<uint32_t> ids_all;
+  std::vector<uint8_t> free_all;
   for (int w = 0; w < 2; ++w) {
     d->n_if[w] = cnt[w];
     if (!cnt[w]) continue;
     d->ids[w].assign(src_ids[w], src_ids[w] + cnt[w]);
-    std::vector<uint8_t> fr(cnt[w]);
     for (uint32_t i = 0; i < cnt[w]; ++i) {
       if (src_ids[w][i] >= n_dofs) {
         set_error("mfgpu_dist_create: interface dof out of range");
         return fail(MFGPU_EINVAL);
       }
-      fr[i] = con[src_ids[w][i]] ? 0 : 1;
+      ids_all.push_back(src_ids[w][i]);
+      free_all.push_back(con[src_ids[w][i]] ? 0 : 1);
     }
-    const size_t vb = (size_t)cnt[w] * esize(number_type);
-    if (hipMalloc((void **)&d->d_ids[w], (size_t)cnt[w] * 4) != hipSuccess || hipMalloc((void **)&d->d_free[w], cnt[w]) != hipSuccess ||
-        hipMalloc(&d->d_send[w], vb) != hipSuccess || hipMalloc(&d->d_recv[w], vb) != hipSuccess ||
-        hipMemcpy(d->d_ids[w], src_ids[w], (size_t)cnt[w] * 4, hipMemcpyHostToDevice) != hipSuccess ||
-        hipMemcpy(d->d_free[w], fr.data(), cnt[w], hipMemcpyHostToDevice) != hipSuccess) {
+  }
+  const size_t n_all = ids_all.size(), es = esize(number_type);
+  if (n_all) {
+    if (hipMalloc(&d->d_base[0], n_all * 4) != hipSuccess || hipMalloc(&d->d_base[1], n_all) != hipSuccess ||
+        hipMalloc(&d->d_base[2], n_all * es) != hipSuccess || hipMalloc(&d->d_base[3], n_all * es) != hipSuccess ||
+        hipMemcpy(d->d_base[0], ids_all.data(), n_all * 4, hipMemcpyHostToDevice) != hipSuccess ||
+        hipMemcpy(d->d_base[1], free_all.data(), n_all, hipMemcpyHostToDevice) != hipSuccess) {
       set_error("mfgpu_dist_create: device allocation failed");
       return fail(MFGPU_ENOMEM);
+    }
+    for (int w = 0; w < 2; ++w) {
+      const size_t off = w ? cnt[0] : 0;
+      d->d_ids[w] = (uint32_t *)d->d_base[0] + off;
+      d->d_free[w] = (uint8_t *)d->d_base[1] + off;
+      d->d_send[w] = (char *)d->d_base[2] + off * es;
+      d->d_recv[w] = (char *)d->d_base[3] + off * es;
     }
   }
   // highest priority: the exchange's short kernels (pass 2 of the planes, pack, RCCL's send / recv) should get wave
@@ -299,8 +312,7 @@ int mfgpu_vmult_dist_begin(mfgpu_handle *h, mfgpu_dist *d, void *dst, const void
   if (d->interface_first && (uint32_t)handle_n_batches(h) == d->n_batches) {
     // SURVEY.md 8e steps 1-3.  The side stream writes dst on the interface planes only (pass 2 of the priority dofs);
     // the interior batches and the rest of pass 2 write every other entry: no two streams touch the same entry.
-    int rc = handle_cells_range(h, 0, d->r1_end, dst, src, stream, 0);
-    if (!rc) rc = handle_cells_range(h, d->r2_begin, d->n_batches, dst, src, stream, 0);
+    int rc = handle_cells_two_ranges(h, 0, d->r1_end, d->r2_begin, d->n_batches, dst, src, stream, 0);
     if (rc) return rc;
     HIP_TRY(hipEventRecord(d->ev_if, st));
     HIP_TRY(hipStreamWaitEvent(d->side, d->ev_if, 0));
@@ -342,13 +354,9 @@ int mfgpu_vmult_dist(mfgpu_handle *h, mfgpu_dist *d, void *dst, const void *src,
 void mfgpu_dist_destroy(mfgpu_dist *d) {
   if (!d) return;
   if (d->comm) ncclCommDestroy(d->comm);
-  for (int w = 0; w < 2; ++w) {
-    hipFree(d->d_ids[w]);
-    hipFree(d->d_free[w]);
-    hipFree(d->d_send[w]);
-    hipFree(d->d_recv[w]);
+  for (int w = 0; w < 2; ++w)
     if (d->local_peer[w]) d->local_peer[w]->local_peer[1 - w] = nullptr;
-  }
+  for (void *p : d->d_base) hipFree(p);
   if (d->side) hipStreamDestroy(d->side);
   if (d->ev_packed) hipEventDestroy(d->ev_packed);
   if (d->ev_done) hipEventDestroy(d->ev_done);

@@ -167,6 +167,8 @@ int handle_n_batches(const mfgpu_handle *h);
 bool handle_ranged_ok(const mfgpu_handle *h);
 int handle_batches_touching(const mfgpu_handle *h, const uint32_t *ids, uint32_t n, std::vector<uint8_t> &flags);
 int handle_cells_range(mfgpu_handle *h, uint32_t b0, uint32_t b1, void *dst, const void *src, void *stream, int add);
+int handle_cells_two_ranges(mfgpu_handle *h, uint32_t b0, uint32_t b1, uint32_t c0, uint32_t c1, void *dst,
+                            const void *src, void *stream, int add);
 int handle_pass2_group(mfgpu_handle *h, int group, void *dst, const void *src, void *stream, int add);
 
 }  // namespace mfgpu

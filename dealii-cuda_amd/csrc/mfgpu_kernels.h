@@ -35,6 +35,7 @@ struct ApplyArgs {
   const T *src;
   uint32_t batch0;     // first batch of this launch (colour)
   uint32_t batch_end;  // one past the last batch of this launch
+  uint32_t hole0 = 0xffffffffu, hole_len = 0;  // plane kernels: batches [hole0, hole0 + hole_len) are skipped
   uint32_t nb_max;  // LDS layout: max dofs per batch
   int add;          // vmult_add semantics
   unsigned long long *stamps;  // diagnostic build only (MFGPU_STAMPS), else nullptr

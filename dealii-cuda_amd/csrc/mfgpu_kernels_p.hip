@@ -76,7 +76,7 @@ apply_planes3(const ApplyArgs<T> A, const TablesEO<T, n> tab) {
   // persistent workgroups, XCD-aware contiguous batch ranges (see apply_batches_x)
   uint32_t b, bstride, bend;
   {
-    const uint32_t nbt = A.batch_end - A.batch0, G = gridDim.x;
+    const uint32_t nbt = A.batch_end - A.batch0 - A.hole_len, G = gridDim.x;
     if (G >= 8 && nbt >= G) {
       const uint32_t xcd = blockIdx.x & 7u, slot = blockIdx.x >> 3;
       const uint32_t q = G >> 3, rem = G & 7u;
@@ -87,12 +87,20 @@ apply_planes3(const ApplyArgs<T> A, const TablesEO<T, n> tab) {
       bstride = w;
     } else {
       b = A.batch0 + blockIdx.x;
-      bend = A.batch_end;
+      bend = A.batch_end - A.hole_len;
       bstride = G;
     }
   }
   if (b >= bend) return;
-  auto next_of = [&](uint32_t x) { return x + bstride < bend ? x + bstride : x; };
+  // The ranges above count the launch's batches without its hole [hole0, hole0 + hole_len) (mfgpu_vmult_dist_begin:
+  // the batches on the two interface planes of a slab in ONE launch; hole_len = 0 otherwise); b, b1, .. are batch
+  // numbers proper.  Scalar arithmetic.
+  const uint32_t hole0 = A.hole0, hole_len = A.hole_len;
+  auto next_of = [&](uint32_t x) {
+    const uint32_t l = (x >= hole0 ? x - hole_len : x) + bstride;
+    return l < bend ? (l >= hole0 ? l + hole_len : l) : x;
+  };
+  if (b >= hole0) b += hole_len;
 
   // Per-batch records have FIXED sizes and a fixed structure (mfgpu_api.hip): every address below is a uniform base
   // (scalar arithmetic on the batch index) plus a lane offset plus an immediate; nothing is clamped per batch and

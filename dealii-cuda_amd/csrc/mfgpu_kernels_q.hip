@@ -77,7 +77,7 @@ __device__ __forceinline__ void planes4_body(const ApplyArgs<T> &A, const Tables
   // persistent workgroups, XCD-aware contiguous batch ranges (see apply_batches_x)
   uint32_t b, bstride, bend;
   {
-    const uint32_t nbt = A.batch_end - A.batch0, G = gridDim.x;
+    const uint32_t nbt = A.batch_end - A.batch0 - A.hole_len, G = gridDim.x;
     if (G >= 8 && nbt >= G) {
       const uint32_t xcd = blockIdx.x & 7u, slot = blockIdx.x >> 3;
       const uint32_t q = G >> 3, rem = G & 7u;
@@ -88,12 +88,20 @@ __device__ __forceinline__ void planes4_body(const ApplyArgs<T> &A, const Tables
       bstride = w;
     } else {
       b = A.batch0 + blockIdx.x;
-      bend = A.batch_end;
+      bend = A.batch_end - A.hole_len;
       bstride = G;
     }
   }
   if (b >= bend) return;
-  auto next_of = [&](uint32_t x) { return x + bstride < bend ? x + bstride : x; };
+  // The ranges above count the launch's batches without its hole [hole0, hole0 + hole_len) (mfgpu_vmult_dist_begin:
+  // the batches on the two interface planes of a slab in ONE launch; hole_len = 0 otherwise); b, b1, .. are batch
+  // numbers proper.  Scalar arithmetic.
+  const uint32_t hole0 = A.hole0, hole_len = A.hole_len;
+  auto next_of = [&](uint32_t x) {
+    const uint32_t l = (x >= hole0 ? x - hole_len : x) + bstride;
+    return l < bend ? (l >= hole0 ? l + hole_len : l) : x;
+  };
+  if (b >= hole0) b += hole_len;
 
   // Per-batch records: fixed sizes, fixed structure (mfgpu_plan.cpp build_plane_records), no per-batch metadata.
   // Vectors and the halo buffer are addressed base + 32-bit byte offset (n_dofs < 2^29; shifting a dof-list entry
