@@ -266,16 +266,26 @@ def main():
         chk = SlabExchange(mesh, rank, world, dev, tdt, "allreduce")
         xs = torch.linspace(0.5, 1.5, N_loc, device=dev, dtype=tdt)
         y1, y2 = torch.empty_like(xs), torch.empty_like(xs)
-        cxx.vmult(op, y1, xs, stream)
-        op.vmult(y2, xs, stream)
-        chk.exchange_add(y2)
-        torch.cuda.synchronize()
-        err = float((y1 - y2).norm() / y2.norm())
+        err = float("inf")
+        try:
+            cxx.vmult(op, y1, xs, stream)
+            torch.cuda.synchronize()
+            op.vmult(y2, xs, stream)
+            chk.exchange_add(y2)
+            torch.cuda.synchronize()
+            err = float((y1 - y2).norm() / y2.norm())
+        except (mf.MfgpuError, RuntimeError) as e:
+            print(f"[bench] rank {rank}: mfgpu_vmult_dist failed ({e})", file=sys.stderr)
         bad = torch.tensor([0.0 if err <= (1e-5 if args.float else 1e-12) else 1.0], device=dev)
         dist.all_reduce(bad, op=dist.ReduceOp.MAX)
-        if bad.item() != 0.0:
-            raise SystemExit("mfgpu_vmult_dist disagrees with the all-reduce exchange of the interface planes")
-        del chk, xs, y1, y2
+        del xs, y1, y2
+        if bad.item() != 0.0:  # all ranks or none: time the torch.distributed exchange instead, and say so in the line
+            print(f"[bench] rank {rank}: mfgpu_vmult_dist failed or disagrees with the all-reduce exchange of the "
+                  f"interface planes (rel. error {err:.3e}); falling back to --mode p2p", file=sys.stderr)
+            cxx = None
+            args.mode = "p2p"
+            exch = SlabExchange(mesh, rank, world, dev, tdt, "p2p")
+        del chk
     elif world > 1 and exch is None:
         exch = SlabExchange(mesh, rank, world, dev, tdt, args.mode)
 

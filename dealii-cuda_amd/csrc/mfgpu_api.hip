@@ -38,6 +38,7 @@ struct mfgpu_handle {
   // apply_planes3: fixed-size per-batch records (see ApplyArgs)
   uint32_t *d_bdofsp = nullptr, *d_idxp = nullptr;
   uint32_t *d_hnrec = nullptr;  // apply_planes3<HN>: per-batch records of the hanging-node line operations
+  uint32_t *d_hn_slot = nullptr;  // ... and per plane batch the index of its record (0xffffffff: none)
   void *d_coefp = nullptr;
   void *d_coef = nullptr;
   uint32_t *d_cmask = nullptr, *d_orphans = nullptr;
@@ -232,8 +233,10 @@ int create_arrays(mfgpu_handle *h, const mfgpu_desc &d) {
   }
   if (h->pk) {
     if ((rc = build_plane_records(h->plan, d.constraint_mask))) return rc;
-    if (!P.pr_hn.empty())
+    if (!P.pr_hn.empty()) {
       if ((rc = dev_upload(&h->d_hnrec, P.pr_hn.data(), P.pr_hn.size() * 4, acct))) return rc;
+      if ((rc = dev_upload(&h->d_hn_slot, P.pr_hn_slot.data(), P.pr_hn_slot.size() * 4, acct))) return rc;
+    }
     if ((rc = dev_upload(&h->d_bdofsp, P.pr_dofs.data(), P.pr_dofs.size() * 4, acct))) return rc;
     if ((rc = dev_upload(&h->d_idxp, P.pr_idx.data(), P.pr_idx.size() * 4, acct))) return rc;
   }
@@ -405,8 +408,8 @@ int create_arrays(mfgpu_handle *h, const mfgpu_desc &d) {
 // Segments of the cell loop (see mfgpu_handle::seg_end).  request = mfgpu_desc.cell_loop_segments: 0 the library's
 // choice, 1 one segment (pass 2 strictly after the cell loop), k > 1 k segments of equal batch counts.  The choice:
 // where two kernel families share the mesh (plane batches | pencil batches of the cells with a hanging-node mask) the
-// family boundary -- the launch boundary exists anyway (C3: 0.381 instead of 0.392 ms per vmult); ONE segment
-// otherwise.  Measured on C2 (profiles/r02_notes.md section 6): with the last 4 of 13 grid iterations as a second
+// family boundary -- the launch boundary exists anyway (C3 in round 2: 0.381 instead of 0.392 ms per vmult); two halves
+// on hanging-node meshes at p = 4 (below); ONE segment otherwise.  Measured on C2 (profiles/r02_notes.md section 6): with the last 4 of 13 grid iterations as a second
 // segment the two kernels do run side by side, but the cell loop slows down by what pass 2 takes (58.6 instead of
 // 37 us for the segment; both are short of issue slots and memory latency, not of different resources), and the event
 // record / cross-stream waits add three pipeline drains of 5-12 us per vmult: 0.171 instead of 0.156 ms.
@@ -422,6 +425,11 @@ void choose_segments(mfgpu_handle *h, uint32_t request) {
   if (request > 1) {
     for (uint32_t i = 1; i < request; ++i) cuts.push_back((uint32_t)((uint64_t)nb * i / request));
   }
+  // hanging-node meshes at p = 4 (batches of masked and unmasked cells interleaved, one instantiation): pass 2 also
+  // writes the identity rows of the eliminated hanging-node dofs and is a third of the cell loop's time; its first
+  // half beside the second half of the cell loop measures 0.267-0.269 instead of 0.274-0.278 ms on C3 (three segments:
+  // 0.280; at p = 3: no difference) -- profiles/r03_notes.md section 8
+  if (request == 0 && h->pk && !P.pr_hn.empty() && nplain == 0 && P.n == 5) cuts.push_back(nb / 2);
   std::sort(cuts.begin(), cuts.end());
   h->seg_end.clear();
   for (uint32_t c : cuts)
@@ -528,7 +536,7 @@ ApplyArgs<T> make_args(mfgpu_handle *h, void *dst, const void *src, int add) {
   a.bdofsp = h->d_bdofsp;
   a.idxp = h->d_idxp;
   a.hnrec = h->d_hnrec;
-  a.hn_batch0 = P.n_plain_plane_batches;
+  a.hn_slot = h->d_hn_slot;
   a.coefp = (const T *)h->d_coefp;
   a.coef = (const T *)h->d_coef;
   a.cmask = h->d_cmask;
@@ -732,8 +740,9 @@ int handle_cells_range(mfgpu_handle *h, uint32_t b0, uint32_t b1, void *dst, con
 // batches [b0, b1) and [c0, c1), b1 <= c0: one launch with a hole when both lie in the plain plane batches
 int handle_cells_two_ranges(mfgpu_handle *h, uint32_t b0, uint32_t b1, uint32_t c0, uint32_t c1, void *dst,
                             const void *src, void *stream, int add) {
-  const uint32_t nplain = h->pk ? h->plan.n_plain_plane_batches : 0u;
-  if (b0 >= b1 || c0 >= c1 || b1 > c0 || c1 > nplain) {
+  const uint32_t nplain = h->pk ? h->plan.n_plain_plane_batches : 0u, npl = h->pk ? h->plan.n_plane_batches : 0u;
+  const bool plain = c1 <= nplain, masked = b0 >= nplain && c1 <= npl;  // both ranges in one instantiation's batches
+  if (b0 >= b1 || c0 >= c1 || b1 > c0 || !(plain || masked)) {
     const int rc = handle_cells_range(h, b0, b1, dst, src, stream, add);
     return rc ? rc : handle_cells_range(h, c0, c1, dst, src, stream, add);
   }
@@ -745,7 +754,8 @@ int handle_cells_two_ranges(mfgpu_handle *h, uint32_t b0, uint32_t b1, uint32_t 
     a.hole_len = c0 - b1;
     const uint32_t nbat = (b1 - b0) + (c1 - c0);
     using T = typename std::remove_const<typename std::remove_pointer<decltype(a.src)>::type>::type;
-    HIP_TRY(planes_launch<T>(h, a, false, nbat < h->max_grid_p ? nbat : h->max_grid_p, st, false, nullptr, nullptr));
+    const uint32_t cap = plain ? h->max_grid_p : h->max_grid_ph;
+    HIP_TRY(planes_launch<T>(h, a, !plain, nbat < cap ? nbat : cap, st, false, nullptr, nullptr));
     return 0;
   };
   return h->number_type == MFGPU_F64 ? run(make_args<double>(h, dst, src, add)) : run(make_args<float>(h, dst, src, add));
@@ -846,6 +856,7 @@ void mfgpu_destroy(mfgpu_handle *h) {
   hipFree(h->d_bdofsp);
   hipFree(h->d_idxp);
   hipFree(h->d_hnrec);
+  hipFree(h->d_hn_slot);
   hipFree(h->d_coefp);
   hipFree(h->d_constrained);
   hipFree(h->d_tab2);
@@ -916,7 +927,15 @@ int mfgpu_plan_stats(const mfgpu_handle *h, uint64_t s[8]) {
   s[6] = P.n_first;
   s[7] = P.n_add;
   if (h->twopass) {  // two-pass mode reports shared dofs / halo partial sums instead
-    s[1] = 1;
+    // cell-loop launches per vmult: per segment one for each kernel instantiation that owns batches of it
+    const uint32_t nb = (uint32_t)s[0], npl = h->pk ? P.n_plane_batches : 0u, nplain = h->pk ? P.n_plain_plane_batches : 0u;
+    const uint32_t edge[4] = {0u, nplain, npl, nb};
+    s[1] = 0;
+    for (size_t g = 0; g < h->seg_end.size(); ++g) {
+      const uint32_t s0 = g ? h->seg_end[g - 1] : 0u, s1 = h->seg_end[g];
+      for (int f = 0; f < 3; ++f)
+        if (std::max(s0, edge[f]) < std::min(s1, edge[f + 1])) ++s[1];
+    }
     s[6] = P.sdofs.size();
     s[7] = P.halo_off.back();
   }

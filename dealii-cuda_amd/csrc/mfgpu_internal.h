@@ -95,11 +95,14 @@ struct Plan {
   std::vector<uint32_t> chunks;           // [4 * n_chunks] {sdofs position, count | k << 16, gstarts offset, offset in group}
   std::vector<uint32_t> gstarts;          // per group: halo slot of its first dof in each of its k touchers
   uint32_t max_batch_dofs = 0, max_batch_cells = 0;
-  uint32_t n_plane_batches = 0;  // the first n_plane_batches batches run in apply_planes3, the rest in apply_batches_x
-  uint32_t n_plain_plane_batches = 0;  // ... of which the first n_plain_plane_batches hold cells without a mask only
-  // apply_planes3 (build_plane_records): fixed-size per-batch records -- dof lists, index runs, and for the batches of
-  // masked cells the hanging-node records
-  std::vector<uint32_t> pr_dofs, pr_idx, pr_hn;
+  uint32_t n_plane_batches = 0;  // the first n_plane_batches batches run in the plane kernels, the rest in apply_batches_x
+  // ... of which the first n_plain_plane_batches hold cells without a mask only (plain instantiation); the others run
+  // in the <HN> instantiation.  With PlanLimits::masked_planes the batches of masked and of unmasked cells are NOT
+  // sorted apart (one launch, creation order = spatial order): 0 as soon as one batch has a masked cell.
+  uint32_t n_plain_plane_batches = 0;
+  // plane kernels (build_plane_records): fixed-size per-batch records -- dof lists, index runs, and for the batches
+  // of masked cells the hanging-node records; pr_hn_slot[b] = index of batch b's record in pr_hn, or 0xffffffff
+  std::vector<uint32_t> pr_dofs, pr_idx, pr_hn, pr_hn_slot;
   uint64_t n_first = 0, n_add = 0;
 };
 
@@ -111,11 +114,12 @@ struct PlanLimits {
   // never constrained); the rest -- at most shared_max, else the plan fails with MFGPU_EUNSUPPORTED -- takes the
   // pass-2 route, and every batch has at least one pass-2 dof; every batch owns halo_stride halo slots
   uint32_t interior_max = 0, shared_max = 0, halo_stride = 0;
-  // meshes with hanging nodes: batches of unmasked cells only (plane kernel) first, then batches of masked cells
-  // under the pencil kernel's limits (see build_plan)
+  // meshes with hanging nodes: a batch holds masked cells only or unmasked cells only; the batches of unmasked cells
+  // (plane kernel) come first, then the batches of masked cells under the pencil kernel's limits (see build_plan)
   bool segregate_masked = false;
-  // ... or, with masked_planes, also as plane batches (apply_planes3<HN>): same slot structure, and at most
-  // private_max private entries per batch for the cells' constrained nodes
+  // ... or, with masked_planes, the masked cells' batches are plane batches too (<HN> instantiation): same slot
+  // structure, at most private_max private entries per batch for the cells' constrained nodes, and the two kinds
+  // of batches stay interleaved in creation order (ONE launch of the <HN> instantiation walks them all)
   bool masked_planes = false;
   uint32_t private_max = 0;
 };

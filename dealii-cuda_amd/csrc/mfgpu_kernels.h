@@ -23,7 +23,7 @@ struct ApplyArgs {
   const T *coefp;          // [n*n rows][NT tasks] folded coefficient
   // apply_planes3<HN> (batches hn_batch0 ..): fixed-size records of p_hn_rows(n) x 64 words (mfgpu_internal.h)
   const uint32_t *hnrec;
-  uint32_t hn_batch0;
+  const uint32_t *hn_slot;  // per plane batch: index of its record in hnrec, or 0xffffffff (cells without a mask)
   const T *coef;          // folded a*J0^2*JxW (apply_batches_g: the 6 entries of a*JxW*J*J^T), plan cell order
   const uint32_t *cmask;  // plan cell order, or nullptr
   const T *hn_weights;    // [n*n] W[i*n+j] (device), or nullptr

@@ -162,9 +162,15 @@ apply_planes3(const ApplyArgs<T> A, const TablesEO<T, n> tab) {
   constexpr int CR = PRIV / 64, HROWS = HN ? p_hn_rows(n) : 1;
   uint32_t Hc[HROWS], Hn[HROWS];  // HN: this batch's and the next batch's hanging-node record
   auto load_hn = [&](uint32_t bb, uint32_t (&H)[HROWS]) {
-    const uint32_t *p = A.hnrec + (size_t)(bb - A.hn_batch0) * (HROWS * 64) + lane;
+    const uint32_t slot = A.hn_slot[bb];  // uniform
+    if (slot != 0xffffffffu) {
+      const uint32_t *p = A.hnrec + (size_t)slot * (HROWS * 64) + lane;
 #pragma unroll
-    for (int w = 0; w < HROWS; ++w) H[w] = nt_load(p + w * 64);
+      for (int w = 0; w < HROWS; ++w) H[w] = nt_load(p + w * 64);
+    } else {  // a batch of cells without a mask: no copies, no line operations
+#pragma unroll
+      for (int w = 0; w < HROWS; ++w) H[w] = 0u;
+    }
   };
   T Cc[n2];
   T SVn[KGU], R[KGU], old[KGU];
@@ -236,7 +242,7 @@ apply_planes3(const ApplyArgs<T> A, const TablesEO<T, n> tab) {
         }
       }
     };
-    if (HN) {
+    if (HN && hn_ncopy) {  // (uniform; a batch of cells without a mask has no copies)
 #pragma unroll
       for (int r = 0; r < CR; ++r) {
         if ((uint32_t)(r * 64) >= hn_ncopy) break;  // uniform
@@ -444,7 +450,7 @@ apply_planes3(const ApplyArgs<T> A, const TablesEO<T, n> tab) {
     WaveSync::sync();
     STAMP(4);
 
-    if (HN) {
+    if (HN && hn_ncopy) {
       // the transposed passes in reverse order, then the private entries' sums go to their dofs' entries
       hn_pass(2, true);
       WaveSync::sync();

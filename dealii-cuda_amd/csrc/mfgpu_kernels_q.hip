@@ -153,9 +153,15 @@ __device__ __forceinline__ void planes4_body(const ApplyArgs<T> &A, const Tables
   constexpr int CR = PRIV / 64, HROWS = HN ? p_hn_rows(n) : 1;
   uint32_t Hc[HROWS];  // HN: this batch's hanging-node record
   auto load_hn = [&](uint32_t bb, uint32_t (&H)[HROWS]) {
-    const uint32_t *p = A.hnrec + (size_t)(bb - A.hn_batch0) * (HROWS * 64) + lane;
+    const uint32_t slot = A.hn_slot[bb];  // uniform
+    if (slot != 0xffffffffu) {
+      const uint32_t *p = A.hnrec + (size_t)slot * (HROWS * 64) + lane;
 #pragma unroll
-    for (int w = 0; w < HROWS; ++w) H[w] = nt_load(p + w * 64);
+      for (int w = 0; w < HROWS; ++w) H[w] = nt_load(p + w * 64);
+    } else {  // a batch of cells without a mask: no copies, no line operations
+#pragma unroll
+      for (int w = 0; w < HROWS; ++w) H[w] = 0u;
+    }
   };
   load_dofs(b, Gc);
   load_ix(b, IXc);
@@ -215,7 +221,7 @@ __device__ __forceinline__ void planes4_body(const ApplyArgs<T> &A, const Tables
         }
       }
     };
-    if (HN) {
+    if (HN && hn_ncopy) {  // (uniform; a batch of cells without a mask has no copies)
 #pragma unroll
       for (int r = 0; r < CR; ++r) {
         if ((uint32_t)(r * 64) >= hn_ncopy) break;  // uniform
@@ -393,7 +399,7 @@ __device__ __forceinline__ void planes4_body(const ApplyArgs<T> &A, const Tables
       lds_add(reinterpret_cast<double *>(reinterpret_cast<char *>(ua) + ixb(IXc, i)), (double)w[i]);
     WaveSync::sync();
 
-    if (HN) {
+    if (HN && hn_ncopy) {
       // the transposed passes in reverse order, then the private entries' sums go to their dofs' entries
       hn_pass(2, true);
       WaveSync::sync();

@@ -315,7 +315,7 @@ int build_plan(const mfgpu_desc &d, Plan &P, uint32_t max_chunks, const PlanLimi
     cells.resize(last_ok);
     if (seed < nc && cell_batch[seed] != b) seed = 0;  // defensive: the seed is the first cell of its batch
   }
-  if (segregate) {  // plane batches first (stable)
+  if (segregate && !masked_planes) {  // plane batches first (stable)
     std::vector<uint32_t> idx(batches.size());
     std::iota(idx.begin(), idx.end(), 0u);
     std::stable_sort(idx.begin(), idx.end(), [&](uint32_t a, uint32_t b2) { return batch_masked[a] < batch_masked[b2]; });
@@ -327,7 +327,7 @@ int build_plan(const mfgpu_desc &d, Plan &P, uint32_t max_chunks, const PlanLimi
     }
     batches.swap(sorted_batches);
     batch_masked.swap(sorted_masked);
-  } else {
+  } else if (!segregate) {
     batch_masked.assign(batches.size(), 0);
   }
   uint32_t nb = (uint32_t)batches.size();
@@ -534,11 +534,14 @@ int build_plan(const mfgpu_desc &d, Plan &P, uint32_t max_chunks, const PlanLimi
     P.max_batch_cells = std::max<uint32_t>(P.max_batch_cells, (uint32_t)batches[b].size());
   }
   P.n_plane_batches = P.n_plain_plane_batches = 0;
-  if (interior_max)
+  if (interior_max) {
     for (uint32_t k = 0; k < nb; ++k) {
       P.n_plain_plane_batches += batch_masked[order[k]] ? 0u : 1u;
       P.n_plane_batches += (batch_masked[order[k]] && !masked_planes) ? 0u : 1u;
     }
+    // masked_planes: the two kinds are interleaved, every plane batch runs in the <HN> instantiation
+    if (masked_planes && P.n_plain_plane_batches < P.n_plane_batches) P.n_plain_plane_batches = 0;
+  }
   P.orphans.clear();
   for (uint32_t g = 0; g < N; ++g)
     if (!touched[g]) P.orphans.push_back(g | (constrained[g] ? 0x80000000u : 0u));
@@ -601,18 +604,18 @@ int build_plane_records(Plan &P, const uint32_t *constraint_mask) {
   bd.assign((size_t)NB * nbat, 0u);
   ix.assign((size_t)NIW * NT * nbat, dummy | (dummy << 16));
   std::vector<uint32_t> slot_of;  // batch-local id (position in P.bdofs) -> slot
-  // batches of cells WITH a hanging-node mask (apply_planes3<HN>, the plan's batches n_plain_plane_batches ..): the
+  // batches of cells WITH a hanging-node mask (<HN> instantiation; anywhere behind the first n_plain_plane_batches): the
   // constrained nodes of a cell (those on a line one of the interpolation passes of hanging_nodes.cuh:617-696
   // touches) get PRIVATE positions behind the dof list; the cell's index runs point there.  Per batch: a copy list
   // (private position <- position of the node's dof in the list) and per direction the line operations, each the n
   // private positions of a line in the order the plain weight matrix applies to (hn_cell_lines).
   const int HROWS = p_hn_rows(n), CR = p_priv_max(n) / 64;
   std::vector<uint32_t> &hnrec = P.pr_hn;
-  hnrec.assign((size_t)(nbat - P.n_plain_plane_batches) * HROWS * 64, 0u);
+  hnrec.clear();
+  P.pr_hn_slot.assign(nbat, 0xffffffffu);
   std::vector<HnLine> lines[3];
   std::vector<uint16_t> pnodes;
   std::vector<uint32_t> priv_pos((size_t)P.nd);
-  const uint32_t npl_plain = P.n_plain_plane_batches;
   for (size_t b = 0; b < nbat; ++b) {
     const uint32_t c0 = P.batch_cell_off[b], nc = P.batch_cell_off[b + 1] - c0;
     const uint32_t d0 = P.batch_dof_off[b], nbd = P.batch_dof_off[b + 1] - d0, ni = P.batch_nint[b];
@@ -628,7 +631,9 @@ int build_plane_records(Plan &P, const uint32_t *constraint_mask) {
       else src_t = std::min<uint32_t>(ni + (uint32_t)(t - JI), nbd - 1);
       bd[b * NB + t] = P.bdofs[d0 + src_t];
     }
-    const bool hnb = b >= npl_plain;
+    bool hnb = false;  // (a batch holds masked cells only or unmasked cells only)
+    if (constraint_mask && b >= P.n_plain_plane_batches)
+      for (uint32_t c = 0; c < nc; ++c) hnb = hnb || constraint_mask[P.cell_order[c0 + c]] != 0;
     uint32_t next_priv = (uint32_t)NB;
     std::vector<uint32_t> copies, ops_d[3];
     for (uint32_t c = 0; c < nc; ++c) {
@@ -662,7 +667,9 @@ int build_plane_records(Plan &P, const uint32_t *constraint_mask) {
         }
     }
     if (hnb) {
-      uint32_t *rec = hnrec.data() + (size_t)(b - npl_plain) * HROWS * 64;
+      P.pr_hn_slot[b] = (uint32_t)(hnrec.size() / ((size_t)HROWS * 64));
+      hnrec.resize(hnrec.size() + (size_t)HROWS * 64, 0u);
+      uint32_t *rec = hnrec.data() + (size_t)P.pr_hn_slot[b] * HROWS * 64;
       for (size_t e = 0; e < copies.size(); ++e) rec[e] = copies[e];  // rows 0 .. CR-1, entry e at [e / 64][e % 64]
       for (int dir = 0; dir < 3; ++dir) {
         const size_t nops = ops_d[dir].size() / 3;
@@ -826,6 +833,7 @@ int64_t mfgpu_plan_array_u32(const mfgpu_plan *p, int what, const uint32_t **ptr
     case 13: v = &p->plan.pr_dofs; break;
     case 14: v = &p->plan.pr_idx; break;
     case 15: v = &p->plan.pr_hn; break;
+    case 16: v = &p->plan.pr_hn_slot; break;
     default: mfgpu::set_error("bad array id"); return MFGPU_EINVAL;
   }
   *ptr = v->data();

@@ -390,6 +390,7 @@ class Plan:
     pr_dofs = property(lambda s: s._u32(13))   # dof lists, bit 31 = constrained
     pr_idx = property(lambda s: s._u32(14))    # index runs
     pr_hn = property(lambda s: s._u32(15))     # hanging-node records of the batches of masked cells
+    pr_hn_slot = property(lambda s: s._u32(16))  # per plane batch: index of its record in pr_hn, or 0xffffffff
 
     @property
     def lmap(self):

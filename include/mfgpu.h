@@ -165,6 +165,7 @@ void mfgpu_plan_destroy(mfgpu_plan *p);
  *       11 chunks[4*n_chunks] {sdofs position, count | k<<16, gstarts offset, offset in group} 12 gstarts
  *       plane plans (apply_planes3): 13 dof-list records [n_plane_batches * slots * 64] 14 index-run records
  *       15 hanging-node records of the batches of masked cells (layout: mfgpu_internal.h p_hn_rows)
+ *       16 per plane batch the index of its record in 15, or 0xffffffff (a batch of cells without a mask)
  * returns element count, *ptr = host pointer valid until mfgpu_plan_destroy                  */
 int64_t mfgpu_plan_array_u32(const mfgpu_plan *p, int what, const uint32_t **ptr);
 int64_t mfgpu_plan_lmap(const mfgpu_plan *p, const uint16_t **ptr);   /* [n_cells*n^dim], plan order */

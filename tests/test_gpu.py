@@ -336,6 +336,9 @@ def test_adaptive_mesh_both_cell_loop_kernels(p, nref, xk):
     op = mf.Operator(mesh.desc, mesh)
     auto = {4: "apply_planes3", 3: "apply_planes4", 2: "apply_batches_x"}[p]  # (p = 3 in double: apply_planes4)
     assert op.kernel_name() == (auto if xk else "apply_batches")
+    # batches of masked and unmasked cells interleaved, ONE instantiation: one launch (p = 4: two halves, pass 2 of the
+    # first beside the second); p = 2: plane-less, the pencil kernel in one launch
+    assert op.plan_stats()["n_launches"] == (2 if (p == 4 and xk) else 1)
     rng = np.random.default_rng(5)
     x, y0 = rng.standard_normal(mesh.n_dofs), rng.standard_normal(mesh.n_dofs)
     assert rel(gpu_vmult(op, x), o.vmult(od, x)) <= 1e-12
@@ -351,6 +354,7 @@ def test_adaptive_mesh_high_degree_two_families(p, nref, nt):
     od = oracle_desc_from_mesh(mesh, dtype=np.float64)
     op = mf.Operator(mesh.desc, mesh)
     assert op.kernel_name() == "apply_planes4+apply_batches_x"
+    assert op.plan_stats()["n_launches"] == 2  # the two families, pass 2 of the first's dofs beside the second
     rng = np.random.default_rng(p)
     x, y0 = rng.standard_normal(mesh.n_dofs), rng.standard_normal(mesh.n_dofs)
     xt, y0t = (v.astype(mf.np_dtype(nt)).astype(np.float64) for v in (x, y0))

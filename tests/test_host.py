@@ -226,6 +226,13 @@ def test_plane_records_on_the_adaptive_mesh():
     od = oracle_desc_from_mesh(mesh)
     plan = mf.Plan(mesh.desc, mesh)
     assert len(plan.pr_hn) > 0
+    # batches of masked and of unmasked cells stay interleaved in creation order: ONE launch walks them all
+    masked = plan.pr_hn_slot != 0xffffffff
+    assert masked.any() and (~masked).any() and np.any(masked[:-1] & ~masked[1:]) and np.any(~masked[:-1] & masked[1:])
+    cm = mesh.arrays()["constraint_mask"][plan.cell_order]
+    bco = plan.batch_cell_off
+    for b in range(len(masked)):
+        assert np.all((cm[bco[b]:bco[b + 1]] != 0) == masked[b])  # a batch holds one kind of cells only
     x = np.random.default_rng(1).standard_normal(od.n_dofs)
     ref = o.vmult(od, x)
     np.testing.assert_allclose(emulate_plane_records_vmult(od, plan, x), ref, rtol=0, atol=1e-12 * np.abs(ref).max())

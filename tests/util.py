@@ -134,7 +134,8 @@ def emulate_plane_records_vmult(od: o.Desc, plan: "mf.Plan", src, dst_in=None):
     bd = plan.pr_dofs.reshape(nbat, NB)
     ixw = plan.pr_idx.reshape(nbat, NIW, NT)
     hn = plan.pr_hn.reshape(-1, HROWS, 64)
-    nplain = nbat - hn.shape[0]
+    hn_slot = plan.pr_hn_slot  # batches of masked and of unmasked cells are interleaved (one launch)
+    assert len(hn_slot) == nbat and sorted(hn_slot[hn_slot != 0xffffffff]) == list(range(hn.shape[0]))
     W = o.constraint_weights(od.degree).reshape(n, n)
     hoff = plan.halo_off
     add = dst_in is not None
@@ -151,8 +152,8 @@ def emulate_plane_records_vmult(od: o.Desc, plan: "mf.Plan", src, dst_in=None):
         ua = np.zeros(NB + PRIV)
         ua[:NB] = np.where(con, 0.0, src[g])
         copies, ops = [], [[], [], []]
-        if b >= nplain:
-            rec = hn[b - nplain]
+        if hn_slot[b] != 0xffffffff:
+            rec = hn[hn_slot[b]]
             ncopy, cnt = int(rec[HROWS - 2, 0] & 0xffff), [int(rec[HROWS - 2, 0] >> 16), int(rec[HROWS - 1, 0] & 0xffff), int(rec[HROWS - 1, 0] >> 16)]
             assert np.all(rec[HROWS - 2] == rec[HROWS - 2, 0]) and np.all(rec[HROWS - 1] == rec[HROWS - 1, 0])
             flat = rec[:CR].reshape(-1)[:ncopy]

@@ -12,12 +12,13 @@ import numpy as np  # noqa: E402
 
 import pymfgpu as mf  # noqa: E402
 
-n = int(sys.argv[1]) if len(sys.argv) > 1 else 54
+adaptive = len(sys.argv) > 1 and sys.argv[1].startswith("adaptive:")  # adaptive:NREF -> the bmop ADAPTIVE_GRID mesh
+n = 54 if adaptive or len(sys.argv) < 2 else int(sys.argv[1])
 p = int(sys.argv[2]) if len(sys.argv) > 2 else 4
 nv = int(sys.argv[3]) if len(sys.argv) > 3 else 3  # vmults before the stamps are read (the last one's are kept)
-mesh = mf.Mesh.uniform(3, p, n)
+mesh = mf.Mesh.adaptive(3, p, int(sys.argv[1].split(":")[1])) if adaptive else mf.Mesh.uniform(3, p, n)
 op = mf.Operator(mesh.desc, mesh)
-assert op.kernel_name() == "apply_planes3"
+assert op.kernel_name().startswith("apply_planes3"), op.kernel_name()
 L = mf.lib()
 L.mfgpu_debug_stamps.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t]
 assert L.mfgpu_debug_stamps(op._h, None, 0) == 0
@@ -39,6 +40,12 @@ print(f"{ok.sum()} batches; cycles per batch: mean {tot.mean():.0f}, p10 {np.per
 for k in range(1, 8):
     d = S[:, k] - S[:, k - 1]
     print(f"  {names[k-1]:>20s} -> {names[k]:<20s} mean {d.mean():8.0f} cyc ({100 * d.mean() / tot.mean():5.1f} %)  p90 {np.percentile(d, 90):8.0f}")
+if adaptive:  # by tenth of the batch order (plain batches first, then the batches of cells with a mask)
+    idx = np.nonzero(ok)[0]
+    for t in range(10):
+        m = (idx >= nbt * t // 10) & (idx < nbt * (t + 1) // 10)
+        d = np.diff(S[m][:, :8], axis=1).mean(axis=0)
+        print(f"  batches {nbt * t // 10:6d}..: {tot[m].mean():7.0f} cyc = " + " | ".join(f"{x:5.0f}" for x in d))
 rt = (S[:, 9] - S[:, 8])
 good = rt > 0
 print(f"in-kernel clock (cycles / 100 MHz ticks): {100e6 * tot[good].sum() / rt[good].sum() / 1e9:.3f} GHz;"
