@@ -188,7 +188,12 @@ def main():
     tdt = torch.float32 if args.float else torch.float64
     s = 4 if args.float else 8
     p = args.degree
+    # weak scaling: the global cube has ~world x the cells; with the default cell count (a multiple of 6) the edge stays a
+    # multiple of 6, which the 3x2x2-cell batches of p = 4 tile without ragged batches (54, 66, 84, 108 cells for
+    # 1, 2, 4, 8 GPUs: C4 at 8); bench.py --cells 64 runs 9 % below --cells 66 for that reason
     n_glob = int(round(args.cells * world ** (1.0 / 3.0)))
+    if world > 1 and args.cells % 6 == 0:
+        n_glob = 6 * int(round(args.cells * world ** (1.0 / 3.0) / 6.0))
     zb, ze = slab_ranges(n_glob, world)[rank]
     if args.ball >= 0:
         if world != 1:
