@@ -215,7 +215,9 @@ apply_planes3(const ApplyArgs<T> A, const TablesEO<T, n> tab) {
       const uint32_t w = dir == 0 ? Hc[HROWS - 2] >> 16 : dir == 1 ? Hc[HROWS - 1] & 0xffffu : Hc[HROWS - 1] >> 16;
       return (uint32_t)__builtin_amdgcn_readfirstlane(w);
     };
-    auto hn_pass = [&](int dir, bool transposed) {
+    // (Wr: the weight matrix in registers, read from LDS once per group of three passes instead of 25 broadcast reads
+    // per line operation, which tripled the LDS instructions of a hanging-node batch)
+    auto hn_pass = [&](int dir, bool transposed, const double (&Wr)[n2]) {
       const uint32_t count = hn_count(dir);
 #pragma unroll
       for (int r = 0; r < kHnOpRounds; ++r) {
@@ -233,7 +235,7 @@ apply_planes3(const ApplyArgs<T> A, const TablesEO<T, n> tab) {
         for (int i = 0; i < n; ++i) {
           double acc = 0.0;
 #pragma unroll
-          for (int k2 = 0; k2 < n; ++k2) acc = fma(transposed ? Wl[k2 * n + i] : Wl[i * n + k2], v[k2], acc);
+          for (int k2 = 0; k2 < n; ++k2) acc = fma(transposed ? Wr[k2 * n + i] : Wr[i * n + k2], v[k2], acc);
           o[i] = acc;
         }
         if (on) {
@@ -243,17 +245,23 @@ apply_planes3(const ApplyArgs<T> A, const TablesEO<T, n> tab) {
       }
     };
     if (HN && hn_ncopy) {  // (uniform; a batch of cells without a mask has no copies)
+      double Wr[n2];
 #pragma unroll
-      for (int r = 0; r < CR; ++r) {
-        if ((uint32_t)(r * 64) >= hn_ncopy) break;  // uniform
-        if ((uint32_t)(r * 64 + lane) < hn_ncopy) ua[Hc[r] >> 16] = ua[Hc[r] & 0xffffu];
-      }
+      for (int i = 0; i < n2; ++i) Wr[i] = Wl[i];
+      // all reads, then all writes: rounds beyond the count run with no lane active instead of ending the loop on a
+      // uniform branch, which would put an LDS round trip between every two of them
+      double cv[CR > 0 ? CR : 1];
+#pragma unroll
+      for (int r = 0; r < CR; ++r) cv[r] = (uint32_t)(r * 64 + lane) < hn_ncopy ? ua[Hc[r] & 0xffffu] : 0.0;
+#pragma unroll
+      for (int r = 0; r < CR; ++r)
+        if ((uint32_t)(r * 64 + lane) < hn_ncopy) ua[Hc[r] >> 16] = cv[r];
       WaveSync::sync();
-      hn_pass(0, false);
+      hn_pass(0, false, Wr);
       WaveSync::sync();
-      hn_pass(1, false);
+      hn_pass(1, false, Wr);
       WaveSync::sync();
-      hn_pass(2, false);
+      hn_pass(2, false, Wr);
       WaveSync::sync();
     }
     STAMP(0);
@@ -452,17 +460,21 @@ apply_planes3(const ApplyArgs<T> A, const TablesEO<T, n> tab) {
 
     if (HN && hn_ncopy) {
       // the transposed passes in reverse order, then the private entries' sums go to their dofs' entries
-      hn_pass(2, true);
-      WaveSync::sync();
-      hn_pass(1, true);
-      WaveSync::sync();
-      hn_pass(0, true);
-      WaveSync::sync();
+      double Wr[n2];
 #pragma unroll
-      for (int r = 0; r < CR; ++r) {
-        if ((uint32_t)(r * 64) >= hn_ncopy) break;  // uniform
-        if ((uint32_t)(r * 64 + lane) < hn_ncopy) lds_add(ua + (Hc[r] & 0xffffu), ua[Hc[r] >> 16]);
-      }
+      for (int i = 0; i < n2; ++i) Wr[i] = Wl[i];
+      hn_pass(2, true, Wr);
+      WaveSync::sync();
+      hn_pass(1, true, Wr);
+      WaveSync::sync();
+      hn_pass(0, true, Wr);
+      WaveSync::sync();
+      double cv[CR > 0 ? CR : 1];
+#pragma unroll
+      for (int r = 0; r < CR; ++r) cv[r] = (uint32_t)(r * 64 + lane) < hn_ncopy ? ua[Hc[r] >> 16] : 0.0;
+#pragma unroll
+      for (int r = 0; r < CR; ++r)
+        if ((uint32_t)(r * 64 + lane) < hn_ncopy) lds_add(ua + (Hc[r] & 0xffffu), cv[r]);
       WaveSync::sync();
     }
     // ---- batch results -> registers (stored during the next iteration); the next batch's gathered values -> LDS:
