@@ -70,4 +70,4 @@ def test_bench_multi_rank_path_on_one_gpu(fake_rccl):
     assert pr.returncode == 0, pr.stderr[-3000:]
     d = json.loads(pr.stdout.strip().split("\n")[-1])
     assert d["n_gpus"] == 2 and d["config"]["parallelism"] == "slab2/cxx" and d["config"]["finite"]
-    assert d["config"]["cells_per_dir"] == 15 and d["value"] > 0  # round(12 * 2^(1/3)) cells per direction (weak scaling)
+    assert d["config"]["cells_per_dir"] == 18 and d["value"] > 0  # 12 * 2^(1/3) to a multiple of 6 (weak scaling)
