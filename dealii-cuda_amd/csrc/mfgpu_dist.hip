@@ -108,13 +108,22 @@ int start_exchange(mfgpu_dist *d, hipStream_t st) {
   if (st != d->side) HIP_TRY(hipStreamWaitEvent(d->side, d->ev_packed, 0));
   const ncclDataType_t dt = d->number_type == MFGPU_F64 ? ncclDouble : ncclFloat;
   NCCL_TRY(ncclGroupStart());
-  for (int w = 0; w < 2; ++w) {
+  // (a failing call must not leave the group open: the group depth is state of the calling thread, and an open group
+  // would defer every later RCCL call of this process, the caller's own included)
+  ncclResult_t bad = ncclSuccess;
+  for (int w = 0; w < 2 && bad == ncclSuccess; ++w) {
     if (!d->n_if[w]) continue;
     const int peer = w == 0 ? d->rank - 1 : d->rank + 1;
-    NCCL_TRY(ncclSend(d->d_send[w], d->n_if[w], dt, peer, d->comm, d->side));
-    NCCL_TRY(ncclRecv(d->d_recv[w], d->n_if[w], dt, peer, d->comm, d->side));
+    bad = ncclSend(d->d_send[w], d->n_if[w], dt, peer, d->comm, d->side);
+    if (bad == ncclSuccess) bad = ncclRecv(d->d_recv[w], d->n_if[w], dt, peer, d->comm, d->side);
   }
-  NCCL_TRY(ncclGroupEnd());
+  const ncclResult_t end = ncclGroupEnd();
+  if (bad != ncclSuccess || end != ncclSuccess) {
+    set_error(std::string("grouped ncclSend / ncclRecv with the slab's neighbours: ") +
+              ncclGetErrorString(bad != ncclSuccess ? bad : end));
+    d->in_flight = false;
+    return MFGPU_EHIP;
+  }
   HIP_TRY(hipEventRecord(d->ev_done, d->side));
   return 0;
 }

@@ -71,3 +71,20 @@ def test_bench_multi_rank_path_on_one_gpu(fake_rccl):
     d = json.loads(pr.stdout.strip().split("\n")[-1])
     assert d["n_gpus"] == 2 and d["config"]["parallelism"] == "slab2/cxx" and d["config"]["finite"]
     assert d["config"]["cells_per_dir"] == 18 and d["value"] > 0  # 12 * 2^(1/3) to a multiple of 6 (weak scaling)
+
+
+@pytest.mark.parametrize("fault", ["error", "corrupt"])
+def test_bench_falls_back_when_the_rccl_path_fails(fake_rccl, fault):
+    """the first multi-GPU run is also the first run of the RCCL transport: if its grouped send / recv fails, or its result
+    disagrees with the dense all-reduce of the interface planes, bench.py times the torch.distributed exchange of the
+    test double instead and says so in the line (the library closes the RCCL group it opened before it reports the
+    error, so the process's later collectives are not deferred)"""
+    import json
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    env.update(LD_PRELOAD=fake_rccl, MFGPU_BENCH_TEST_ONE_GPU="1", FAKE_RCCL_FAULT=fault)
+    pr = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "3", "--warmup", "1",
+                         "--cells", "12", "--no-cpu"], env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=600)
+    assert pr.returncode == 0, pr.stderr[-3000:]
+    d = json.loads(pr.stdout.strip().split("\n")[-1])
+    assert d["n_gpus"] == 2 and d["config"]["parallelism"] == "slab2/p2p" and d["config"]["finite"] and d["value"] > 0
+    assert "falling back to --mode p2p" in pr.stderr
