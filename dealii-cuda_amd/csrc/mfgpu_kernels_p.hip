@@ -279,18 +279,18 @@ apply_planes3(const ApplyArgs<T> A, const TablesEO<T, n> tab) {
     // The scattered accesses (gather of the next batch's source values, stores of the PREVIOUS batch's results) and
     // the coefficient rows are spread over the compute steps below, one or two per step: a 64-address gather or
     // scatter occupies the memory pipeline for ~150 cycles and a lone wave per SIMD has nothing else to hide it with.
-    auto hookA = [&](int s) {  // 2 n steps: the gather of the next batch
-      MFGPU_PIN_VMEM();
-#pragma unroll
-      for (int j = (KGU * s) / (2 * n); j < (KGU * (s + 1)) / (2 * n); ++j)
-        SVn[j] = src_at(Gn[j]);
-      MFGPU_PIN_VMEM();
-    };
-    auto hookB = [&](int s) {  // 5 n steps: the previous batch's scatter
+    // Stage B is where the arithmetic is (8 of the 14 contractions, 25 steps): it takes the scatter AND the gather, one
+    // or two instructions per step; stage A, short and behind the burst of coalesced loads above, takes none (with the
+    // gather in stage A, two per step: +4 us per vmult on C2, profiles/r03_notes.md section 10).
+    auto hookA = [&](int) {};
+    auto hookB = [&](int s) {  // 5 n steps: the previous batch's scatter, the gather of the next batch
       MFGPU_PIN_VMEM();
 #pragma unroll
       for (int j = (KGU * s) / (5 * n); j < (KGU * (s + 1)) / (5 * n); ++j)
         scatter_slot(j, bp, Gp[j], R[j], old[j]);
+#pragma unroll
+      for (int j = (KGU * s) / (5 * n); j < (KGU * (s + 1)) / (5 * n); ++j)
+        SVn[j] = src_at(Gn[j]);
       MFGPU_PIN_VMEM();
     };
     const T *const cnext = A.coefp + (size_t)b1 * (n2 * NT) + tk;
