@@ -210,9 +210,10 @@ apply_planes3(const ApplyArgs<T> A, const TablesEO<T, n> tab) {
     // ---- hanging-node batches: private copies of the constrained nodes, then the interpolation passes x, y, z.
     // The batch's record (copies, line operations, counts) was requested one batch ahead with the other coalesced
     // loads; lanes beyond a count work on nothing.
-    const uint32_t hn_ncopy = HN ? (uint32_t)__builtin_amdgcn_readfirstlane(Hc[HROWS - 2] & 0xffffu) : 0u;
+    constexpr int kH2 = HN ? HROWS - 2 : 0, kH1 = HN ? HROWS - 1 : 0;  // the record's two rows of counts
+    const uint32_t hn_ncopy = HN ? (uint32_t)__builtin_amdgcn_readfirstlane(Hc[kH2] & 0xffffu) : 0u;
     auto hn_count = [&](int dir) -> uint32_t {
-      const uint32_t w = dir == 0 ? Hc[HROWS - 2] >> 16 : dir == 1 ? Hc[HROWS - 1] & 0xffffu : Hc[HROWS - 1] >> 16;
+      const uint32_t w = dir == 0 ? Hc[kH2] >> 16 : dir == 1 ? Hc[kH1] & 0xffffu : Hc[kH1] >> 16;
       return (uint32_t)__builtin_amdgcn_readfirstlane(w);
     };
     // (Wr: the weight matrix in registers, read from LDS once per group of three passes instead of 25 broadcast reads
