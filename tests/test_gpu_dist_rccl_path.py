@@ -66,7 +66,7 @@ def test_bench_multi_rank_path_on_one_gpu(fake_rccl):
     env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
     env.update(LD_PRELOAD=fake_rccl, MFGPU_BENCH_TEST_ONE_GPU="1")
     pr = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "3", "--warmup", "1",
-                         "--cells", "12", "--no-cpu"], env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=600)
+                         "--cells", "12", "--no-cpu", "--ramp-steps", "20"], env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=600)
     assert pr.returncode == 0, pr.stderr[-3000:]
     d = json.loads(pr.stdout.strip().split("\n")[-1])
     assert d["n_gpus"] == 2 and d["config"]["parallelism"] == "slab2/cxx" and d["config"]["finite"]
@@ -83,7 +83,7 @@ def test_bench_falls_back_when_the_rccl_path_fails(fake_rccl, fault):
     env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
     env.update(LD_PRELOAD=fake_rccl, MFGPU_BENCH_TEST_ONE_GPU="1", FAKE_RCCL_FAULT=fault)
     pr = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "3", "--warmup", "1",
-                         "--cells", "12", "--no-cpu"], env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=600)
+                         "--cells", "12", "--no-cpu", "--ramp-steps", "20"], env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=600)
     assert pr.returncode == 0, pr.stderr[-3000:]
     d = json.loads(pr.stdout.strip().split("\n")[-1])
     assert d["n_gpus"] == 2 and d["config"]["parallelism"] == "slab2/p2p" and d["config"]["finite"] and d["value"] > 0
