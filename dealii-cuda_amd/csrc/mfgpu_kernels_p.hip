@@ -306,9 +306,12 @@ apply_planes3(const ApplyArgs<T> A, const TablesEO<T, n> tab) {
     // ---- stage A: gather the plane, S_y, then per line S_x and D_x
     {
       T u[n2];
+      // (read in the order the first contraction consumes: line x = 0 first)
 #pragma unroll
-      for (int i = 0; i < n2; ++i)
-        u[i] = (T) * reinterpret_cast<const double *>(reinterpret_cast<const char *>(ua) + ixb(IXc, i));
+      for (int x = 0; x < n; ++x)
+#pragma unroll
+        for (int y = 0; y < n; ++y)
+          u[x + n * y] = (T) * reinterpret_cast<const double *>(reinterpret_cast<const char *>(ua) + ixb(IXc, x + n * y));
 #pragma unroll
       for (int x = 0; x < n; ++x) {
         T in[n], out[n];
@@ -449,12 +452,12 @@ apply_planes3(const ApplyArgs<T> A, const TablesEO<T, n> tab) {
         T in[n], out[n];
         get_line<n, 1>(o, x, in);
         eo_apply<n, 1>(tab, in, out);
-        set_line<n, 1>(o, x, out);
+        // a finished line goes to the accumulator at once: its LDS atomics run under the next line's contraction
+#pragma unroll
+        for (int y = 0; y < n; ++y)
+          lds_add(reinterpret_cast<double *>(reinterpret_cast<char *>(ua) + ixb(IXc, x + n * y)), (double)out[y]);
         hookC(n + x);
       }
-#pragma unroll
-      for (int i = 0; i < n2; ++i)
-        lds_add(reinterpret_cast<double *>(reinterpret_cast<char *>(ua) + ixb(IXc, i)), (double)o[i]);
     }
     WaveSync::sync();
     STAMP(4);
