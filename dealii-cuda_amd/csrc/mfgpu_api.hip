@@ -176,6 +176,17 @@ int upload_pass2(mfgpu_handle *h, const uint32_t *priority, uint32_t n_priority)
     std::vector<uint32_t> arr, tiles;
     build_pass2_classes(sd[g], so[g], si[g], arr, tiles);
     h->n_p2tiles[g] = (uint32_t)(tiles.size() / 4);
+    // Tile order = the order the workgroups of pass 2 are dispatched in.  The builder's order is ascending in the
+    // position of a dof's first toucher; while the halo buffer fits the 256 MB Infinity Cache the REVERSE is faster --
+    // the partial sums the cell loop wrote last are read first, from cache: pass 2 42.4 -> 41.3 us on C2, 38.9 -> 35.3
+    // on C5, -1 .. -3 % per vmult up to 38 M dofs; beyond (n = 96: 57 M dofs, 340 MB of partial sums) it is slower, at
+    // 81 M dofs by 10 % (profiles/r03_notes.md section 13)
+    const size_t esz = h->number_type == MFGPU_F64 ? 8 : 4;
+    if ((size_t)P.halo_off.back() * esz <= ((size_t)256 << 20)) {
+      const size_t nt = tiles.size() / 4;
+      for (size_t a = 0, b = nt ? nt - 1 : 0; a < b; ++a, --b)
+        for (int w = 0; w < 4; ++w) std::swap(tiles[4 * a + w], tiles[4 * b + w]);
+    }
     size_t acct = 0;
     int rc;
     if ((rc = dev_upload(&h->d_p2arr[g], arr.data(), arr.size() * 4, acct))) return rc;
