@@ -280,6 +280,11 @@ __device__ __forceinline__ void planes4_body(const ApplyArgs<T> &A, const Tables
     WaveSync::sync();
 
     // ---- S2 (yz): x-derivative part, t' = S_z^T (c .* S_z b), in place
+    // p = 5 (one wave per SIMD): the next batch's index runs are requested here, not among the 63 loads of S5 (cell loop
+    // 120 -> 116 us at 10^7 dofs); at p = 6 the 25 registers they hold through S4 are 20 spills (147 -> 136 us lost)
+    constexpr bool kIxInS2 = n == 6;
+    uint32_t IXn[NIW];
+    const uint32_t *const ixnext = A.idxp + (size_t)b1 * (NIW * NT) + tk;
 #pragma unroll
     for (int y = 0; y < n; ++y) {
       T in[n], g[n], o[n];
@@ -291,6 +296,12 @@ __device__ __forceinline__ void planes4_body(const ApplyArgs<T> &A, const Tables
       eo_apply<n, 1>(tab, g, o);
 #pragma unroll
       for (int z = 0; z < n; ++z) Tw[pyz + n * y + ZS * z] = o[z];
+      if (kIxInS2) {
+        MFGPU_PIN_VMEM();
+#pragma unroll
+        for (int i = (NIW * y) / n; i < (NIW * (y + 1)) / n; ++i) IXn[i] = nt_load(ixnext + i * NT);
+        MFGPU_PIN_VMEM();
+      }
     }
     WaveSync::sync();
 
@@ -363,18 +374,18 @@ __device__ __forceinline__ void planes4_body(const ApplyArgs<T> &A, const Tables
     // The requests are spread over the 2 n steps of S5, pinned between its contractions (only LDS instructions may
     // cross the pins): issued in one burst they block the wave for ~7 k cycles (125 cycles per instruction: eight
     // waves share the CU's one address unit), spread out they are issued while the wave computes.
-    uint32_t IXn[NIW], Hn[HROWS];
+    uint32_t Hn[HROWS];
     if (HN) load_hn(b1, Hn);
     const T *const cnext = A.coefp + (size_t)b1 * (n2 * NT) + tk;
-    const uint32_t *const ixnext = A.idxp + (size_t)b1 * (NIW * NT) + tk;
     auto hook = [&](int s) {  // step s of 2 n: gathers first (consumed first), then index runs, then coefficient rows
-      constexpr int NL = KGU + NIW + (kCoefInS1 ? 0 : n2);
+      constexpr int NIX = kIxInS2 ? 0 : NIW;
+      constexpr int NL = KGU + NIX + (kCoefInS1 ? 0 : n2);
       MFGPU_PIN_VMEM();
 #pragma unroll
       for (int i = (NL * s) / (2 * n); i < (NL * (s + 1)) / (2 * n); ++i) {
         if (i < KGU) SV[i] = src_at(Gn[i]);
-        else if (i < KGU + NIW) IXn[i - KGU] = nt_load(ixnext + (i - KGU) * NT);
-        else if (!kCoefInS1) Cc[i - KGU - NIW] = nt_load(cnext + (i - KGU - NIW) * NT);
+        else if (i < KGU + NIX) IXn[i - KGU] = nt_load(ixnext + (i - KGU) * NT);
+        else if (!kCoefInS1) Cc[i - KGU - NIX] = nt_load(cnext + (i - KGU - NIX) * NT);
       }
       MFGPU_PIN_VMEM();
     };
