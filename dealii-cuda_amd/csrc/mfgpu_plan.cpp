@@ -226,22 +226,72 @@ int build_plan(const mfgpu_desc &d, Plan &P, uint32_t max_chunks, const PlanLimi
     dc.resize(w);
   }
 
-  // ---- greedy batching: grow from the lowest unassigned cell, always adding the candidate that
-  // shares most dofs with the batch (ties: earliest discovered), until a limit is hit.
-  // With limits->interior_max (apply_planes3) a batch must also keep its SURFACE within the pass-2 slots of the dof
-  // list: surface = dofs with an incident cell outside the batch, or constrained, plus the interior dofs beyond
-  // interior_max.  The surface is not monotone in the number of cells, so growth runs to the cell / dof limit and
-  // the batch is then cut back to the longest prefix of its growth order that satisfied the bound.
+  // ---- batching.  A batch starts at the lowest unassigned cell -- as a BOX of cells where the mesh offers one (plane
+  // plans; see below) -- and grows greedily: always the candidate that shares most dofs with the batch (ties: earliest
+  // discovered), until a limit is hit.  With limits->interior_max (plane kernels) a batch must also keep its SURFACE
+  // within the pass-2 slots of the dof list: surface = dofs with an incident cell outside the batch, or constrained,
+  // plus the interior dofs beyond interior_max.  The surface is not monotone in the number of cells, so growth runs to
+  // the cell / dof limit and the batch is then cut back to the longest prefix of its growth order that satisfied the
+  // bound.
   constexpr uint32_t NONE = 0xffffffffu;
   const bool bound_surface_any = limits && limits->interior_max;
   auto masked = [&](uint32_t c) { return segregate && d.constraint_mask[c] != 0; };
+
+  // Face neighbours by direction (plane plans, n >= 3): the cell across face (axis, side) is the other cell of a dof in
+  // the interior of that face, provided it lists the dof at the mirrored position (same size, same orientation; a
+  // hanging-node face, whose entries were substituted, has no neighbour in this sense).  They let a batch start as a
+  // box a x b x c: on a mesh whose extent is no multiple of the natural box (64 cells: 21 boxes of 3 and one cell over)
+  // greedy growth alone wraps around the row ends and fills the mesh with irregular 9-11-cell batches whose surface
+  // exceeds the dof list (n = 64: 23 340 batches where 21 845 would do; profiles/r03_notes.md section 9).
+  std::vector<uint32_t> nbr;
+  // (conforming meshes only: on the octree meshes with hanging nodes, cells in Morton order and two kinds of cells,
+  // boxes anchored at the lowest unassigned cell leave more single-cell leftovers than they fill batches -- 17 899
+  // against 17 777 batches on C3)
+  const bool use_boxes = bound_surface_any && !segregate && P.dim == 3 && P.n >= 3 && Bmax >= 4;
+  if (use_boxes) {
+    nbr.assign((size_t)nc * 6, NONE);
+    const uint32_t n_ = (uint32_t)P.n, mid = 1;
+    for (uint32_t c = 0; c < nc; ++c)
+      for (uint32_t axis = 0; axis < 3; ++axis)
+        for (uint32_t side = 0; side < 2; ++side) {
+          uint32_t ijk[3] = {mid, mid, mid}, opp[3] = {mid, mid, mid};
+          ijk[axis] = side ? n_ - 1 : 0;
+          opp[axis] = side ? 0 : n_ - 1;
+          const uint32_t li = ijk[0] + n_ * ijk[1] + n_ * n_ * ijk[2], lo = opp[0] + n_ * opp[1] + n_ * n_ * opp[2];
+          const uint32_t g = l2g[(uint64_t)c * nd + li];
+          if (dc_off[g + 1] - dc_off[g] != 2) continue;
+          const uint32_t c2 = dc[dc_off[g]] == c ? dc[dc_off[g] + 1] : dc[dc_off[g]];
+          if (c2 != c && l2g[(uint64_t)c2 * nd + lo] == g) nbr[(size_t)c * 6 + 2 * axis + side] = c2;
+        }
+  }
+  // box shapes a x b x c (cells along x, y, z) up to the cell limit: most cells first, then the most compact
+  struct Shape {
+    uint32_t a, b, c;
+  };
+  std::vector<Shape> shapes;
+  if (use_boxes) {
+    for (uint32_t a = 1; a <= Bmax; ++a)
+      for (uint32_t b2 = 1; a * b2 <= Bmax; ++b2)
+        for (uint32_t c2 = 1; a * b2 * c2 <= Bmax; ++c2)
+          if (a * b2 * c2 == Bmax) shapes.push_back({a, b2, c2});  // (smaller boxes fragment irregular meshes: the growth does better)
+    auto spread = [](const Shape &s2) { return std::max(s2.a, std::max(s2.b, s2.c)) * 4 + s2.a + s2.b + s2.c; };
+    std::stable_sort(shapes.begin(), shapes.end(), [&](const Shape &x, const Shape &y) {
+      const uint32_t vx = x.a * x.b * x.c, vy = y.a * y.b * y.c;
+      if (vx != vy) return vx > vy;
+      if (spread(x) != spread(y)) return spread(x) < spread(y);
+      return x.a != y.a ? x.a > y.a : x.b > y.b;  // the long side along x: the dofs of a batch are x-runs
+    });
+  }
+
   std::vector<uint8_t> batch_masked;  // per batch: class of its cells (segregate only)
   std::vector<uint32_t> cell_batch(nc, NONE);
-  std::vector<uint32_t> dof_stamp(N, NONE);   // batch id that already contains this dof
+  // state of the batch under construction; `stamp` changes with every (re)build, so nothing is ever cleared
+  std::vector<uint32_t> dof_stamp(N, NONE);   // stamp of the build that already contains this dof
   std::vector<uint32_t> inc_cnt(bound_surface_any ? N : 0, 0);  // incident cells of the dof inside the current batch
   std::vector<uint32_t> gain(nc, 0), gain_stamp(nc, NONE);
-  std::vector<uint32_t> cand;
+  std::vector<uint32_t> cand, box;
   std::vector<std::vector<uint32_t>> batches;
+  uint32_t stamp = 0;
   uint32_t seed = 0;
   while (true) {
     while (seed < nc && cell_batch[seed] != NONE) ++seed;
@@ -253,44 +303,97 @@ int build_plan(const mfgpu_desc &d, Plan &P, uint32_t max_chunks, const PlanLimi
     batch_masked.push_back(cls);
     const bool bound_surface = bound_surface_any && (!cls || masked_planes);
     const uint32_t Bmax_b = cls && !masked_planes ? Bmax1 : Bmax, NBmax_b = cls && !masked_planes ? NBmax1 : NBmax;
-    cand.clear();
     uint32_t ndofs = 0, n_enclosed = 0, npriv = 0;
-    size_t last_ok = 0;
-    uint32_t next = seed;
-    while (true) {
-      // add `next`
-      cell_batch[next] = b;
-      cells.push_back(next);
-      npriv += priv_of(next);
+    auto surface_ok = [&]() {
+      return !bound_surface || ndofs - std::min(n_enclosed, limits->interior_max) <= limits->shared_max;
+    };
+    auto begin_build = [&]() {
+      for (uint32_t c : cells) cell_batch[c] = NONE;
+      cells.clear();
+      cand.clear();
+      ++stamp;
+      ndofs = n_enclosed = npriv = 0;
+    };
+    auto add_cell = [&](uint32_t c) {
+      cell_batch[c] = b;
+      cells.push_back(c);
+      npriv += priv_of(c);
       for (uint32_t i = 0; i < nd; ++i) {
-        const uint32_t g = l2g[(uint64_t)next * nd + i];
-        const bool first = dof_stamp[g] != b;
+        const uint32_t g = l2g[(uint64_t)c * nd + i];
+        const bool first = dof_stamp[g] != stamp;
         if (bound_surface) {
           // (a cell listing one dof twice counts once: compare with the previous entries of this cell)
           bool dup = false;
-          for (uint32_t i2 = 0; i2 < i && !dup; ++i2) dup = l2g[(uint64_t)next * nd + i2] == g;
+          for (uint32_t i2 = 0; i2 < i && !dup; ++i2) dup = l2g[(uint64_t)c * nd + i2] == g;
           if (!dup) {
             if (first) inc_cnt[g] = 0;
             if (++inc_cnt[g] == dc_off[g + 1] - dc_off[g] && !constrained[g]) ++n_enclosed;
           }
         }
         if (!first) continue;
-        dof_stamp[g] = b;
+        dof_stamp[g] = stamp;
         ++ndofs;
         if (Bmax_b == 1) continue;
         for (uint32_t k = dc_off[g]; k < dc_off[g + 1]; ++k) {
           const uint32_t c2 = dc[k];
           if (cell_batch[c2] != NONE || masked(c2) != cls) continue;
-          if (gain_stamp[c2] != b) {
-            gain_stamp[c2] = b;
+          if (gain_stamp[c2] != stamp) {
+            gain_stamp[c2] = stamp;
             gain[c2] = 0;
             cand.push_back(c2);
           }
           gain[c2]++;
         }
       }
-      if (!bound_surface || ndofs - std::min(n_enclosed, limits->interior_max) <= limits->shared_max)
-        last_ok = cells.size();
+    };
+
+    // ---- the box the batch starts as: the first shape whose cells exist from the seed in +x, +y, +z, are unassigned
+    // and of the seed's kind, and which keeps every bound
+    bool boxed = false;
+    if (use_boxes && bound_surface && Bmax_b == Bmax) {
+      for (const Shape &sh : shapes) {
+        box.clear();
+        bool ok = true;
+        uint32_t cz = seed;
+        for (uint32_t k = 0; k < sh.c && ok; ++k) {
+          uint32_t cy = cz;
+          for (uint32_t j = 0; j < sh.b && ok; ++j) {
+            uint32_t cx = cy;
+            for (uint32_t i = 0; i < sh.a && ok; ++i) {
+              if (cx == NONE || cell_batch[cx] != NONE || masked(cx) != cls) {
+                ok = false;
+                break;
+              }
+              box.push_back(cx);
+              cx = nbr[(size_t)cx * 6 + 1];
+            }
+            cy = cy == NONE ? NONE : nbr[(size_t)cy * 6 + 3];
+            if (cy == NONE && j + 1 < sh.b) ok = false;
+          }
+          cz = cz == NONE ? NONE : nbr[(size_t)cz * 6 + 5];
+          if (cz == NONE && k + 1 < sh.c) ok = false;
+        }
+        if (!ok) continue;
+        begin_build();
+        for (uint32_t c : box) add_cell(c);
+        if (ndofs <= NBmax_b && surface_ok() && (!(cls && masked_planes) || npriv <= limits->private_max)) {
+          boxed = true;
+          break;
+        }
+      }
+      if (!boxed) begin_build();
+    } else {
+      begin_build();
+    }
+
+    // ---- greedy growth (from the seed, or on from the box)
+    size_t last_ok = boxed ? cells.size() : 0;
+    uint32_t next = boxed ? NONE : seed;
+    while (true) {
+      if (next != NONE) {
+        add_cell(next);
+        if (surface_ok()) last_ok = cells.size();
+      }
       if (cells.size() >= Bmax_b) break;
       // pick best candidate
       uint32_t best = NONE, best_gain = 0;
