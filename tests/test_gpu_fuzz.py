@@ -23,7 +23,7 @@ def _masks(dim):
     return out
 
 
-@pytest.mark.parametrize("seed", range(120))
+@pytest.mark.parametrize("seed", range(400))
 def test_random_configuration(seed):
     rng = np.random.default_rng(1000 + seed)
     dim = int(rng.choice([2, 3, 3, 3]))
