@@ -192,7 +192,8 @@ def _masks3():
     return out
 
 
-@pytest.mark.parametrize("p,n,kw", [(4, 3, {}), (4, 5, {}), (3, 4, {}), (2, 5, {}), (4, 4, dict(max_cells_per_batch=3))])
+@pytest.mark.parametrize("p,n,kw", [(4, 3, {}), (4, 5, {}), (3, 4, {}), (2, 5, {}), (4, 4, dict(max_cells_per_batch=3)),
+                                    (4, 7, {}), (3, 9, {})])  # (7 and 9 cells: box-seeded batches with leftover columns)
 def test_plane_records_dataflow_with_hanging_node_batches(p, n, kw):
     """the fixed-size records apply_planes3 reads (dof lists, index runs, hanging-node records): numpy emulation of the
     kernel's data flow -- private entries, line-by-line interpolation passes with the plain weight matrix, plain cell
@@ -281,6 +282,19 @@ def test_batching_quality_structured():
         ext = [int(np.ptp(cells // 12 ** d % 12)) + 1 for d in range(3)]
         assert ext == [3, 2, 2], ext
     assert np.diff(plan.batch_dof_off).max() == 13 * 9 * 9 and plan.batch_nint.max() == 11 * 7 * 7
+    # a size the box does not divide: the batches start as boxes (face neighbours by direction from the dof lists), so
+    # the 16th column is batched by itself instead of unravelling the whole mesh into 9-11-cell batches
+    od = o.uniform_mesh_desc(3, 4, 16)
+    desc, keep = desc_from_oracle(od)
+    plan = mf.Plan(desc, keep)
+    sizes = np.diff(plan.batch_cell_off)
+    assert len(sizes) <= 355 and (sizes == 12).sum() >= 300, (len(sizes), np.bincount(sizes))  # (greedy alone: 374 / 171; ideal 341.3)
+    assert sorted(plan.cell_order.tolist()) == list(range(16 ** 3))
+    # p = 6: nine cells per wave, 3x3x1 slabs where the mesh allows
+    od = o.uniform_mesh_desc(3, 6, 6)
+    desc, keep = desc_from_oracle(od)
+    plan = mf.Plan(desc, keep)
+    assert len(plan.batch_cell_off) - 1 == 6 ** 3 // 9
 
 
 def test_slab_meshes_tile_the_global_mesh():
